@@ -1,0 +1,337 @@
+// cg_flow_fast.hpp -- depth-2 FermiNet flow: value z(x), structured Jacobian J = dz/dx, log Psi.
+//
+// Reference semantics: src/flow.py:16-55 (FermiNet), src/logpsi.py:7-33 (logpsi),
+// src/slater.py:4-19 (logslaterdet).  The reference obtains J with jax.jacfwd (n*d dense
+// tangents through the (n,n,tpsize) pair tensor, src/logpsi.py:27-28).  Here J is assembled
+// from its block structure with every d x d block contracted from the
+// *left* first, which removes all h x h work per pair:
+//
+//   J_ik = -U'_i T_ik - V_i diag(sig_t(u_ik)) Wt^T T_ik + B_i G_k         (k != i)
+//   J_ii = I - sum_{k != i} J_ik                                          (translation equivariance)
+//
+//   T_ik  = d t0_ik / d r_ik                     (p x d, 3 non-zeros per column)
+//   R_i   = Wf^T diag(sig(u2_i))                 (d x hs)
+//   U'_i  = (1/n) (Wf^T + R_i Wa^T) diag(sig(u1_i)) W0^T      (d x p)
+//   V_i   = (1/n) R_i Wc^T                       (d x ht)
+//   B_i   = R_i Wb^T                             (d x hs)
+//   G_k   = d gbar / d x_k = (1/n^2) sum_{l != k} [ sig1_k (W0^T T_kl) - sig1_l (W0^T T_lk) ]   (hs x d)
+//
+// Work-item layouts (deterministic: no atomics, every sum has a fixed order):
+//   pair-primal  : item (i,h), serial over j      -> m1_i[h] = mean_j softplus(u_ij[h]),  m0_i
+//   G pass       : item (k,h), serial over l
+//   Jacobian pass: item (i,k), serial over h      -> d x d block, written once
+//
+// theta is the flat ravel_pytree vector of the Haiku tree:
+//   [final.b (d), final.w (hs,d), sp0.b (hs), sp0.w (4d+1,hs), sp1.b (hs), sp1.w (2hs+ht,hs), tp0.b (ht), tp0.w (2d+1,ht)]
+#pragma once
+#include "cg_common.hpp"
+#include "cg_linalg.hpp"
+
+// Offsets (in doubles) into the per-walker LDS arena; filled by the host (cg_layout.hpp).
+struct CgFastLds {
+    int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, total;
+};
+
+template <int D, int HS, int HT>
+struct CgFast {
+    static constexpr int P = 2 * D + 1;
+    static constexpr int o_fb = 0;
+    static constexpr int o_fw = o_fb + D;
+    static constexpr int o_s0b = o_fw + HS * D;
+    static constexpr int o_s0w = o_s0b + HS;
+    static constexpr int o_s1b = o_s0w + (4 * D + 1) * HS;
+    static constexpr int o_s1w = o_s1b + HS;
+    static constexpr int o_t0b = o_s1w + (2 * HS + HT) * HS;
+    static constexpr int o_t0w = o_t0b + HT;
+    static constexpr int NPARAM = o_t0w + P * HT;
+    static constexpr int o_W0 = o_s0w + 2 * D * HS;        // rows of sp0.w that see mean_j t0_ij
+    static constexpr int o_Wa = o_s1w;
+    static constexpr int o_Wb = o_s1w + HS * HS;
+    static constexpr int o_Wc = o_s1w + 2 * HS * HS;
+
+    struct PairF { double s2[D], c2[D], del; };
+
+    // features of r_ij = x_i - x_j from per-particle half-angle tables:
+    //   sin(pi r/L) = sh_i ch_j - ch_i sh_j ; cos(2 pi r/L) = 1 - 2 sin^2 ; sin(2 pi r/L) = 2 sin cos
+    static CG_DEVI void pairfeat(const double* sh, const double* ch, int i, int j, PairF& f) {
+        double d2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const double si = sh[i * D + a], ci = ch[i * D + a], sj = sh[j * D + a], cj = ch[j * D + a];
+            const double s = si * cj - ci * sj, c = ci * cj + si * sj;
+            f.s2[a] = 2.0 * s * c; f.c2[a] = 1.0 - 2.0 * s * s; d2 += s * s;
+        }
+        f.del = sqrt(d2);
+        if (i == j) {       // exact diagonal feature [1..1, 0..0, 0]  (src/flow.py:25: "* (1 - eye)")
+#pragma unroll
+            for (int a = 0; a < D; ++a) { f.s2[a] = 0.0; f.c2[a] = 1.0; }
+            f.del = 0.0;
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // primal pass: fills sh,ch,m0,s1,sg1,m1,gbar,cb,sg2,s2,z in LDS.
+    // ---------------------------------------------------------------------------------------
+    static CG_DEVI void primal(const CgBlk& b, const double* __restrict__ th, const double* x /*LDS n*D*/,
+                               int n, double L, double* lds, const CgFastLds& o) {
+        double *sh = lds + o.sh, *ch = lds + o.ch, *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1,
+               *m1 = lds + o.m1, *gbar = lds + o.gbar, *cb = lds + o.cb, *sg2 = lds + o.sg2, *s2 = lds + o.s2,
+               *z = lds + o.z;
+        const double rn = 1.0 / (double)n;
+        for (int e = b.tid; e < n * D; e += b.nthr) {
+            double s, c; sincos(x[e] * (CG_PI / L), &s, &c);
+            sh[e] = s; ch[e] = c;
+        }
+        b.sync();
+        // pair-primal: item (i,h)
+        constexpr int HM = HT > P ? HT : P;          // lanes h < P also carry one raw-feature mean
+        for (int e = b.tid; e < n * HM; e += b.nthr) {
+            const int i = e / HM, h = e - i * HM;
+            double wt[P], bt = 0.0;
+            const bool do_t = h < HT;
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = do_t ? th[o_t0w + f * HT + h] : 0.0;
+            if (do_t) bt = th[o_t0b + h];
+            double acc = 0.0, raw = 0.0;
+            for (int j = 0; j < n; ++j) {
+                PairF pf; pairfeat(sh, ch, i, j, pf);
+                double u = bt;
+#pragma unroll
+                for (int a = 0; a < D; ++a) u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                u += wt[2 * D] * pf.del;
+                if (do_t) acc += softplus_only(u);
+                if (h < P) {
+                    double fv = pf.del;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) { if (h == a) fv = pf.c2[a]; if (h == D + a) fv = pf.s2[a]; }
+                    raw += fv;
+                }
+            }
+            if (do_t) m1[i * HT + h] = acc * rn;
+            if (h < P) m0[i * P + h] = raw * rn;
+        }
+        b.sync();
+        // layer 0 of the one-particle stream: u1_i = W0^T m0_i + b0 (s0 = 0, src/flow.py:16-18,45)
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double u = th[o_s0b + h];
+#pragma unroll
+            for (int f = 0; f < P; ++f) u += th[o_W0 + f * HS + h] * m0[i * P + f];
+            double sp, sg; softplus_sigmoid(u, sp, sg);
+            s1[e] = sp; sg1[e] = sg;
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {
+            double a = 0.0;
+            for (int i = 0; i < n; ++i) a += s1[i * HS + h];
+            gbar[h] = a * rn;
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {
+            double a = th[o_s1b + h];
+#pragma unroll
+            for (int g = 0; g < HS; ++g) a += th[o_Wb + g * HS + h] * gbar[g];
+            cb[h] = a;
+        }
+        b.sync();
+        // last one-particle layer (residual, src/flow.py:51-52)
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double u = cb[h];
+#pragma unroll
+            for (int g = 0; g < HS; ++g) u += th[o_Wa + g * HS + h] * s1[i * HS + g];
+#pragma unroll
+            for (int g = 0; g < HT; ++g) u += th[o_Wc + g * HS + h] * m1[i * HT + g];
+            double sp, sg; softplus_sigmoid(u, sp, sg);
+            sg2[e] = sg; s2[e] = s1[e] + sp;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * D; e += b.nthr) {     // z = x + final(s2), src/flow.py:54-55
+            const int i = e / D, a = e - i * D;
+            double v = x[e] + th[o_fb + a];
+#pragma unroll
+            for (int h = 0; h < HS; ++h) v += th[o_fw + h * D + a] * s2[i * HS + h];
+            z[e] = v;
+        }
+        b.sync();
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // Jacobian assembly (needs primal() results in LDS).  Writes J (N x N, N = n*D, row-major).
+    // ---------------------------------------------------------------------------------------
+    static CG_DEVI void jacobian(const CgBlk& b, const double* __restrict__ th, int n, double L,
+                                 double* lds, const CgFastLds& o) {
+        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2;
+        double *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up, *G = lds + o.G, *J = lds + o.J;
+        const int N = n * D;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        // per-particle left factors: item (i,a,g)
+        for (int e = b.tid; e < n * D * HS; e += b.nthr) {
+            const int i = e / (D * HS), r = e - i * (D * HS), a = r / HS, g = r - a * HS;
+            double ua = th[o_fw + g * D + a], ub = 0.0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) {
+                const double rih = th[o_fw + h * D + a] * sg2[i * HS + h];
+                ua += rih * th[o_Wa + g * HS + h];
+                ub += rih * th[o_Wb + g * HS + h];
+            }
+            U[e] = ua; Bm[e] = ub;
+        }
+        for (int e = b.tid; e < n * D * HT; e += b.nthr) {
+            const int i = e / (D * HT), r = e - i * (D * HT), a = r / HT, g = r - a * HT;
+            double v = 0.0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) v += th[o_fw + h * D + a] * sg2[i * HS + h] * th[o_Wc + g * HS + h];
+            V[e] = v * rn;
+        }
+        // G pass: item (k,h)
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int k = e / HS, h = e - k * HS;
+            double w_c[D], w_s[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) { w_c[a] = th[o_W0 + a * HS + h]; w_s[a] = th[o_W0 + (D + a) * HS + h]; }
+            const double w_d = th[o_W0 + 2 * D * HS + h];
+            const double sgk = sg1[k * HS + h];
+            double acc[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) acc[a] = 0.0;
+            for (int l = 0; l < n; ++l) {
+                if (l == k) continue;
+                PairF pf; pairfeat(sh, ch, k, l, pf);
+                const double rdel = 1.0 / pf.del;
+                const double sgl = sg1[l * HS + h];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double odd = -c1 * pf.s2[bb] * w_c[bb] + c2c * pf.s2[bb] * rdel * w_d;   // odd in r
+                    const double evn = c1 * pf.c2[bb] * w_s[bb];                                  // even in r
+                    // (W0^T T_kl)[h,bb] = odd + evn ;  (W0^T T_lk)[h,bb] = -odd + evn
+                    acc[bb] += sgk * (odd + evn) - sgl * (evn - odd);
+                }
+            }
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) G[(k * HS + h) * D + bb] = acc[bb] * rn * rn;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * D * P; e += b.nthr) {      // U'_i: item (i,a,f)
+            const int i = e / (D * P), r = e - i * (D * P), a = r / P, f = r - a * P;
+            double v = 0.0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) v += U[(i * D + a) * HS + g] * sg1[i * HS + g] * th[o_W0 + f * HS + g];
+            Up[e] = v * rn;
+        }
+        b.sync();
+        // Jacobian pass: item (i,k), k != i
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = e / n, k = e - i * n;
+            if (i == k) continue;
+            PairF pf; pairfeat(sh, ch, i, k, pf);
+            const double rdel = 1.0 / pf.del;
+            double tc[D], ts[D], td[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * pf.s2[bb] * rdel; }
+            double Jb[D][D];
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb)
+                    Jb[a][bb] = -(Up[(i * D + a) * P + bb] * tc[bb] + Up[(i * D + a) * P + D + bb] * ts[bb] +
+                                  Up[(i * D + a) * P + 2 * D] * td[bb]);
+#pragma unroll 4
+            for (int h = 0; h < HT; ++h) {
+                double u = th[o_t0b + h] + th[o_t0w + 2 * D * HT + h] * pf.del;
+                double q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double wc = th[o_t0w + a * HT + h], ws = th[o_t0w + (D + a) * HT + h];
+                    u += wc * pf.c2[a] + ws * pf.s2[a];
+                    q[a] = wc * tc[a] + ws * ts[a] + th[o_t0w + 2 * D * HT + h] * td[a];
+                }
+                const double sg = sigmoid_only(u);
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double vs = V[(i * D + a) * HT + h] * sg;
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) Jb[a][bb] -= vs * q[bb];
+                }
+            }
+#pragma unroll 4
+            for (int g = 0; g < HS; ++g) {
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double bg = Bm[(i * D + a) * HS + g];
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) Jb[a][bb] += bg * G[(k * HS + g) * D + bb];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) J[(i * D + a) * N + k * D + bb] = Jb[a][bb];
+        }
+        b.sync();
+        // diagonal blocks from sum_k J_ik = I
+        for (int e = b.tid; e < n * D * D; e += b.nthr) {
+            const int i = e / (D * D), r = e - i * (D * D), a = r / D, bb = r - a * D;
+            double v = (a == bb) ? 1.0 : 0.0;
+            for (int k = 0; k < n; ++k)
+                if (k != i) v -= J[(i * D + a) * N + k * D + bb];
+            J[(i * D + a) * N + i * D + bb] = v;
+        }
+        b.sync();
+    }
+
+    // ---------------------------------------------------------------------------------------
+    // Slater matrix D_ij = exp(i k_j . z_i) (the L^{-d/2} factor is added analytically)
+    // k_j = 2 pi / L * sp_indices[state_idx[j]]    (src/slater.py:14-17, src/logpsi.py:23)
+    // ---------------------------------------------------------------------------------------
+    static CG_DEVI void slater_matrix(const CgBlk& b, const double* z, const double* __restrict__ spk /*M x D, already * 2pi/L*/,
+                                      const int* __restrict__ sidx, int n, double* Dm) {
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = e / n, j = e - i * n;
+            const double* k = spk + (size_t)sidx[j] * D;
+            double ph = 0.0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) ph += k[a] * z[i * D + a];
+            double s, c; sincos(ph, &s, &c);
+            Dm[2 * e] = c; Dm[2 * e + 1] = s;
+        }
+        b.sync();
+    }
+
+    // log Psi(x) = log phi(z(x)) + 1/2 log|det J|  ->  out = [Re, Im]  (src/logpsi.py:30-31)
+    // also returns the two pieces separately (make_logphi_logjacdet, src/logpsi.py:35-53).
+    static CG_DEVI void logpsi(const CgBlk& b, const double* __restrict__ th, const double* x /*LDS*/,
+                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                               double* lds, const CgFastLds& o, double& re_phi, double& im_phi, double& half_logdetJ) {
+        primal(b, th, x, n, L, lds, o);
+        jacobian(b, th, n, L, lds, o);
+        int* perm = (int*)(lds + o.perm);
+        half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
+        slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+        double la, ar;
+        cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+        re_phi = la - (double)n * (0.5 * D) * log(L);
+        im_phi = ar;
+    }
+};
+
+// host-side layout of the LDS arena (no aliasing beyond Dm <- {U,V,Bm,Up,G} region when `alias_D` is set)
+static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias_D) {
+    CgFastLds o; int P = 2 * D + 1, t = 0;
+    auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
+    o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
+    o.m0 = take(n * P); o.s1 = take(n * HS); o.sg1 = take(n * HS); o.m1 = take(n * HT);
+    o.gbar = take(HS); o.cb = take(HS); o.sg2 = take(n * HS); o.s2 = take(n * HS);
+    int reg = t;
+    o.U = take(n * D * HS); o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P);
+    o.G = take(n * HS * D);
+    int reg_end = t;
+    o.J = take(n * D * n * D);
+    if (alias_D && (reg_end - reg) >= 2 * n * n) { o.Dm = reg; }
+    else if (alias_D) { o.Dm = o.J; }       // large n: Slater matrix reuses J after its LU
+    else o.Dm = take(2 * n * n);
+    o.perm = take((n * D + 1) / 2 + 1);
+    o.total = t;
+    return o;
+}

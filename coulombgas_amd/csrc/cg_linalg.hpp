@@ -1,0 +1,197 @@
+// cg_linalg.hpp -- small dense fp64 linear algebra on one workgroup, operands in LDS.
+//
+// Replaces the reference's jnp.linalg.slogdet / jnp.linalg.inv (LAPACK getrf/getri) call
+// sites: src/logpsi.py:29,50 (real nd x nd Jacobian), src/slater.py:18,38,42 (complex n x n).
+// Partial (row) pivoting like getrf; rows are addressed through a permutation vector so no
+// row is physically swapped.  The pivot search is done redundantly by every thread
+// (broadcast LDS reads) so that no reduction / extra barrier is needed.
+#pragma once
+#include "cg_common.hpp"
+
+// log|det A| of a real N x N matrix (row-major, leading dimension lda) held in LDS.
+// A is destroyed.  perm: int[N] scratch in LDS.  Returns the value in every thread.
+CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* perm, int* sign_out = nullptr) {
+    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
+    b.sync();
+    const int TX = b.nthr < 16 ? b.nthr : 16;
+    const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
+    CgScaledProd prod; prod.init();
+    int sgn = 1;
+    for (int k = 0; k < N; ++k) {
+        int p = k; double best = -1.0;
+        for (int i = k; i < N; ++i) {
+            double v = fabs(A[perm[i] * lda + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        const int rk = perm[p], rk_old = perm[k];
+        b.sync();                                   // all reads of perm done
+        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
+        const double piv = A[rk * lda + k];
+        if (p != k) sgn = -sgn;
+        if (piv < 0) sgn = -sgn;
+        prod.mul(piv);
+        const double rinv = 1.0 / piv;
+        b.sync();                                   // perm update visible
+        for (int i = k + 1 + ty; i < N; i += TY) {
+            const int ri = perm[i];
+            const double l = A[ri * lda + k] * rinv;
+            for (int j = k + 1 + tx; j < N; j += TX) A[ri * lda + j] -= l * A[rk * lda + j];
+        }
+        b.sync();
+    }
+    if (sign_out) *sign_out = sgn;
+    return prod.logabs();
+}
+
+// Complex N x N (interleaved re,im; row-major, lda in complex elements) log det:
+// returns log|det| and arg(det) in (-pi, pi]  (jnp.linalg.slogdet + jnp.log(phase), src/slater.py:18-19)
+CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int* perm,
+                                  double& logabs, double& arg) {
+    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
+    b.sync();
+    const int TX = b.nthr < 16 ? b.nthr : 16;
+    const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
+    CgCplx pm = {1.0, 0.0}; int pe = 0;             // running product, exponent apart
+    for (int k = 0; k < N; ++k) {
+        int p = k; double best = -1.0;
+        for (int i = k; i < N; ++i) {
+            const double* a = A + 2 * (perm[i] * lda + k);
+            double v = a[0] * a[0] + a[1] * a[1];
+            if (v > best) { best = v; p = i; }
+        }
+        const int rk = perm[p], rk_old = perm[k];
+        b.sync();
+        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
+        CgCplx piv = {A[2 * (rk * lda + k)], A[2 * (rk * lda + k) + 1]};
+        pm = cmul(pm, piv);
+        if (p != k) { pm.re = -pm.re; pm.im = -pm.im; }
+        {   // renormalise
+            int ex; double mx = fmax(fabs(pm.re), fabs(pm.im));
+            (void)frexp(mx, &ex);
+            pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex;
+        }
+        const CgCplx rinv = cinv(piv);
+        b.sync();
+        for (int i = k + 1 + ty; i < N; i += TY) {
+            const int ri = perm[i];
+            CgCplx aik = {A[2 * (ri * lda + k)], A[2 * (ri * lda + k) + 1]};
+            CgCplx l = cmul(aik, rinv);
+            for (int j = k + 1 + tx; j < N; j += TX) {
+                double* aij = A + 2 * (ri * lda + j);
+                const double* akj = A + 2 * (rk * lda + j);
+                aij[0] -= l.re * akj[0] - l.im * akj[1];
+                aij[1] -= l.re * akj[1] + l.im * akj[0];
+            }
+        }
+        b.sync();
+    }
+    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = atan2(pm.im, pm.re);
+}
+
+// In-place inverse by Gauss-Jordan with partial pivoting on [A | I] -> [I | A^-1].
+// A: N x N real (lda), Ainv: N x N (ldi) output; A destroyed.  Also returns log|det A|.
+CG_DEVI double cg_inverse_real(const CgBlk& b, double* A, int N, int lda, double* Ainv, int ldi, int* perm) {
+    for (int e = b.tid; e < N * N; e += b.nthr) { int i = e / N, j = e - i * N; Ainv[i * ldi + j] = (i == j) ? 1.0 : 0.0; }
+    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
+    b.sync();
+    const int TX = b.nthr < 16 ? b.nthr : 16;
+    const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
+    CgScaledProd prod; prod.init();
+    for (int k = 0; k < N; ++k) {
+        int p = k; double best = -1.0;
+        for (int i = k; i < N; ++i) {
+            double v = fabs(A[perm[i] * lda + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        const int rk = perm[p], rk_old = perm[k];
+        b.sync();
+        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
+        const double piv = A[rk * lda + k];
+        prod.mul(piv);
+        const double rinv = 1.0 / piv;
+        b.sync();
+        // eliminate column k from every other physical row (Jordan step); pivot row scaled afterwards
+        for (int r = ty; r < N; r += TY) {
+            if (r == rk) continue;
+            const double l = A[r * lda + k] * rinv;
+            for (int j = k + 1 + tx; j < N; j += TX) A[r * lda + j] -= l * A[rk * lda + j];
+            for (int j = tx; j < N; j += TX) Ainv[r * ldi + j] -= l * Ainv[rk * ldi + j];
+        }
+        b.sync();
+        for (int j = b.tid; j < N; j += b.nthr) {
+            if (j > k) A[rk * lda + j] *= rinv;
+            Ainv[rk * ldi + j] *= rinv;
+        }
+        b.sync();
+    }
+    // physical row perm[k] now holds row k of the inverse; un-permute through A as scratch
+    for (int e = b.tid; e < N * N; e += b.nthr) { int k = e / N, j = e - k * N; A[k * lda + j] = Ainv[perm[k] * ldi + j]; }
+    b.sync();
+    for (int e = b.tid; e < N * N; e += b.nthr) { int k = e / N, j = e - k * N; Ainv[k * ldi + j] = A[k * lda + j]; }
+    b.sync();
+    return prod.logabs();
+}
+
+// Complex inverse + log det, same scheme.  A, Ainv interleaved complex.
+CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, double* Ainv, int ldi, int* perm,
+                                double& logabs, double& arg) {
+    for (int e = b.tid; e < N * N; e += b.nthr) {
+        int i = e / N, j = e - i * N;
+        Ainv[2 * (i * ldi + j)] = (i == j) ? 1.0 : 0.0; Ainv[2 * (i * ldi + j) + 1] = 0.0;
+    }
+    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
+    b.sync();
+    const int TX = b.nthr < 16 ? b.nthr : 16;
+    const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
+    CgCplx pm = {1.0, 0.0}; int pe = 0;
+    for (int k = 0; k < N; ++k) {
+        int p = k; double best = -1.0;
+        for (int i = k; i < N; ++i) {
+            const double* a = A + 2 * (perm[i] * lda + k);
+            double v = a[0] * a[0] + a[1] * a[1];
+            if (v > best) { best = v; p = i; }
+        }
+        const int rk = perm[p], rk_old = perm[k];
+        b.sync();
+        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
+        CgCplx piv = {A[2 * (rk * lda + k)], A[2 * (rk * lda + k) + 1]};
+        pm = cmul(pm, piv);
+        if (p != k) { pm.re = -pm.re; pm.im = -pm.im; }
+        { int ex; double mx = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mx, &ex);
+          pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex; }
+        const CgCplx rinv = cinv(piv);
+        b.sync();
+        for (int r = ty; r < N; r += TY) {
+            if (r == rk) continue;
+            CgCplx ark = {A[2 * (r * lda + k)], A[2 * (r * lda + k) + 1]};
+            CgCplx l = cmul(ark, rinv);
+            for (int j = k + 1 + tx; j < N; j += TX) {
+                double* x = A + 2 * (r * lda + j); const double* y = A + 2 * (rk * lda + j);
+                x[0] -= l.re * y[0] - l.im * y[1]; x[1] -= l.re * y[1] + l.im * y[0];
+            }
+            for (int j = tx; j < N; j += TX) {
+                double* x = Ainv + 2 * (r * ldi + j); const double* y = Ainv + 2 * (rk * ldi + j);
+                x[0] -= l.re * y[0] - l.im * y[1]; x[1] -= l.re * y[1] + l.im * y[0];
+            }
+        }
+        b.sync();
+        for (int j = b.tid; j < N; j += b.nthr) {
+            if (j > k) { double* x = A + 2 * (rk * lda + j); CgCplx v = cmul({x[0], x[1]}, rinv); x[0] = v.re; x[1] = v.im; }
+            double* y = Ainv + 2 * (rk * ldi + j); CgCplx w = cmul({y[0], y[1]}, rinv); y[0] = w.re; y[1] = w.im;
+        }
+        b.sync();
+    }
+    for (int e = b.tid; e < N * N; e += b.nthr) {
+        int k = e / N, j = e - k * N;
+        A[2 * (k * lda + j)] = Ainv[2 * (perm[k] * ldi + j)]; A[2 * (k * lda + j) + 1] = Ainv[2 * (perm[k] * ldi + j) + 1];
+    }
+    b.sync();
+    for (int e = b.tid; e < N * N; e += b.nthr) {
+        int k = e / N, j = e - k * N;
+        Ainv[2 * (k * ldi + j)] = A[2 * (k * lda + j)]; Ainv[2 * (k * ldi + j) + 1] = A[2 * (k * lda + j) + 1];
+    }
+    b.sync();
+    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = atan2(pm.im, pm.re);
+}
