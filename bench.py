@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- walker-steps/s of the VMC sampling call on MI355X (BASELINE.json metric).
+
+One "step" = one sampling call of main.py:335 without the Transformer sampler (state_indices supplied):
+mc_steps Metropolis sweeps over B walkers = mc_steps+1 evaluations of logp (src/MCMC.py:36-37), as ONE launch of
+the k_mcmc kernel.  Workload at N=1: BASELINE.json configs[1]: n=13 dim=2 rs=10 Theta=0.15 batch=8192 mc_steps=50.
+With --gpus N the walker batch is sharded (8192 walkers PER GPU, weak scaling, independent chains with distinct
+Philox streams); the only collective is the scalar accept-rate mean (src/MCMC.py:39) over RCCL.
+
+Launch: `python bench.py --gpus 1 --steps K --warmup W` or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+Rank 0 prints ONE JSON line.
+"""
+import argparse, json, os, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_PER_WALKER_STEP = {13: 0.558e6, 29: 2.80e6, 57: 11.4e6}     # SURVEY 8(d) structured count
+BYTES_PER_WALKER_STEP = {13: 484.0, 29: 1060.0, 57: 2068.0}        # SURVEY 8(d), RNG in-kernel
+HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def synthetic(n, dim, B, Emax, rank):
+    """SURVEY 8(d) synthetic inputs."""
+    from tests.common import orbitals, box_length, state_indices
+    L = box_length(n, dim)
+    sp = orbitals(dim, Emax)
+    rng_p = np.random.default_rng(np.random.PCG64(1))
+    from coulombgas_amd.flow import ravel_order
+    theta = np.concatenate([(np.zeros(int(np.prod(s))) if leaf == "b" else 0.01 * rng_p.standard_normal(int(np.prod(s))))
+                            for _, leaf, s in ravel_order(2, 16, 16, dim)])
+    rng = np.random.default_rng(np.random.PCG64(1000 + rank))
+    sidx = state_indices(np.random.default_rng(np.random.PCG64(rank)), B, n, sp.shape[0])
+    x = rng.uniform(0.0, L, (B, n, dim))
+    return L, sp, theta, sidx, x
+
+
+def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=12.0):
+    """Times the CPU restatement (oracle/cg_oracle.c: the algorithm the reference executes -- dense forward-mode
+    Jacobian with n*d tangents, two LU log-dets) on a bounded sample of the same workload, all host cores."""
+    import ctypes as C
+    from coulombgas_amd.build import build_oracle
+    try:
+        path = build_oracle()
+        if path is None:
+            return None
+        lib = C.CDLL(path)
+    except Exception as e:       # no compiler on the box and no prebuilt library
+        return {"value": None, "unit": "walker-steps/s", "error": str(e)}
+    lib.cgo_mcmc.restype = C.c_double
+    lib.cgo_num_threads.restype = C.c_int
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cores = lib.cgo_num_threads()
+
+    def run(Bs, steps):
+        xs = np.ascontiguousarray(x[:Bs]).copy(); ss = np.ascontiguousarray(sidx[:Bs])
+        rng = np.random.default_rng(7)
+        noise = rng.standard_normal((steps, Bs, n, dim)); unif = rng.uniform(size=(steps, Bs))
+        logp = np.empty(Bs)
+        t0 = time.perf_counter()
+        lib.cgo_mcmc(C.c_int(n), C.c_int(dim), C.c_int(16), C.c_int(16), C.c_double(L), p(theta), p(sp), C.c_int(sp.shape[0]),
+                     p(ss), p(xs), C.c_int(Bs), C.c_int(steps), C.c_double(stddev), p(noise), p(unif), p(logp))
+        return time.perf_counter() - t0
+    Bs, steps = min(64 * cores, x.shape[0]), 5
+    t = run(Bs, steps)                                   # calibration (also warm-up)
+    rate = Bs * steps / t
+    Bs2 = int(min(x.shape[0], max(Bs, rate * budget_s / mc_steps // cores * cores)))
+    t2 = run(Bs2, mc_steps)
+    return {"value": Bs2 * mc_steps / t2, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "%d walkers x %d mc_steps of the same workload (n=%d), %.1f s, OpenMP over walkers" % (Bs2, mc_steps, n, t2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=13)
+    ap.add_argument("--batch", type=int, default=8192, help="walkers per GPU")
+    ap.add_argument("--mc_steps", type=int, default=50)
+    ap.add_argument("--mc_stddev", type=float, default=0.1)
+    ap.add_argument("--Emax", type=int, default=25)
+    ap.add_argument("--threads", type=int, default=0, help="threads per walker workgroup (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+            sys.exit(2)
+    dist = None
+    if world > 1:
+        import torch, torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from coulombgas_amd import utils
+    from coulombgas_amd.engine import Engine
+    from coulombgas_amd.comm import RcclComm, NullComm
+    utils.set_device(local)
+    n, dim, B = args.n, 2, args.batch
+    L, sp, theta, sidx, x = synthetic(n, dim, B, args.Emax, rank)
+    eng = Engine(n, dim, 2, 16, 16, L, sp, device=local)
+    eng.set_params(theta)
+    if args.threads:
+        eng.set_block_threads(args.threads)
+    comm = RcclComm(eng, rank, world) if world > 1 else NullComm()
+
+    eng.device_mode(True)
+    d_x = eng.alloc((B, n, dim)).upload(x)
+    d_s = eng.alloc((B, n), np.int32).upload(sidx)
+    d_lp = eng.alloc((B,))
+    d_acc = eng.alloc((16,))
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+            dist.barrier(); torch.cuda.synchronize()
+
+    def sampling_call(it):
+        eng.mcmc_dev(d_x, d_s, B, args.mc_steps, args.mc_stddev, seed=42 + it, walker_offset=rank * B, logp_buf=d_lp)
+        eng.wrap_dev(d_x, B)                                   # src/VMC.py:24
+        if world > 1:                                          # src/MCMC.py:39 pmean of the accept rate
+            rate = eng.mcmc_accepts() / float(args.mc_steps * B)
+            return comm.pmean(rate)
+        return None
+
+    for it in range(args.warmup):                              # thermalisation rounds (main.py:241-246)
+        sampling_call(it)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for it in range(args.steps):
+        eng.timer_start()
+        eng.mcmc_dev(d_x, d_s, B, args.mc_steps, args.mc_stddev, seed=4242 + it, walker_offset=rank * B, logp_buf=d_lp)
+        kernel_ms += eng.timer_stop()                          # HIP events on the kernel's own stream
+        eng.wrap_dev(d_x, B)
+        if world > 1:
+            comm.pmean(eng.mcmc_accepts() / float(args.mc_steps * B))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    accept = eng.mcmc_accepts() / float(args.mc_steps * B)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity of the timed state: finite log-probabilities (a NaN chain would still "run fast")
+    lp = d_lp.download()
+    ok = bool(np.isfinite(lp).all())
+
+    if rank == 0:
+        walker_steps = float(B) * args.mc_steps * args.steps * world
+        value = walker_steps / elapsed
+        k_avg_s = kernel_ms / args.steps * 1e-3
+        fl = FLOPS_PER_WALKER_STEP.get(n)
+        by = BYTES_PER_WALKER_STEP.get(n)
+        eng.device_mode(False)
+        peak_fma = eng.microbench_fp64(0)
+        peak_mfma = eng.microbench_fp64(1)
+        peak = max(peak_fma, peak_mfma)
+        ach = (fl * B * args.mc_steps / k_avg_s / 1e12) if fl else None
+        roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": (ach / peak) if ach else None, "traffic": None,
+                    "kernel": "k_mcmc", "kernel_avg_ms": k_avg_s * 1e3,
+                    "note": "fp64 kernel: peak = measured v_fma_f64 / v_mfma_f64_16x16x4 rate on this GPU (%.1f / %.1f TFLOP/s); "
+                            "achieved = SURVEY 8(d) algorithmic %.3g flop/walker-step x %d walker-steps per launch / HIP-event kernel time"
+                            % (peak_fma, peak_mfma, fl or 0, B * args.mc_steps),
+                    "hbm": {"achieved": (by * B * args.mc_steps / k_avg_s / 1e9) if by else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": (by * B * args.mc_steps / k_avg_s / 1e9 / HBM_PEAK_GBS) if by else None}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            _, _, _, sidx0, x0 = synthetic(n, dim, B, args.Emax, 0)
+            cpu = cpu_baseline(n, dim, L, sp, theta, sidx0, x0, args.mc_steps, args.mc_stddev)
+        out = {"metric": "walker-steps/sec (batch x mcsteps/s), n=%d 2D batch %d" % (n, B), "value": value,
+               "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "n=%d dim=2 rs=10.0 Theta=0.15 Emax=%d batch=%d/GPU mc_steps=%d mc_stddev=%.2f: sampling call "
+                                      "(MCMC chain incl. flow+Jacobian+Slater logp), in-kernel Philox RNG" % (n, args.Emax, B, args.mc_steps, args.mc_stddev),
+                          "walkers_per_gpu": B, "mc_steps": args.mc_steps, "threads_per_walker": eng.launch_info()["threads"],
+                          "lds_bytes_per_walker": eng.launch_info()["lds_bytes"]},
+               "accept_rate": accept, "finite": ok, "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        comm.close()
+        dist.destroy_process_group()
+    eng.close()
+    if not ok:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

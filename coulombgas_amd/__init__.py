@@ -1,0 +1,17 @@
+"""coulombgas_amd -- MI355X-native VMC hot path of fermiflow/CoulombGas.
+
+Exports the names main.py takes from the reference's `src` package for this path
+(src/__init__.py:1-13); everything else of the reference (Transformer sampler, SR optimizer,
+checkpointing, pre-training) is outside the accelerated path."""
+from .flow import FermiNet
+from .potential import kpoints, Madelung, potential_energy
+from .logpsi import (make_logpsi, make_logphi_logjacdet, make_logpsi_grad_laplacian, make_logp,
+                     make_quantum_score)
+from .mcmc import mcmc
+from .vmc import sample_stateindices_and_x, make_loss, make_observable
+from .utils import shard, replicate
+from .engine import Engine
+
+__all__ = ["FermiNet", "kpoints", "Madelung", "potential_energy", "make_logpsi", "make_logphi_logjacdet",
+           "make_logpsi_grad_laplacian", "make_logp", "make_quantum_score", "mcmc",
+           "sample_stateindices_and_x", "make_loss", "make_observable", "shard", "replicate", "Engine"]

@@ -1,0 +1,62 @@
+"""Builds the in-tree native libraries (no JIT cache: the built .so travels with the source tree).
+
+  coulombgas_amd/lib/libcoulombgas_hip.so   gfx950 kernels + C-ABI (include/coulombgas.h)   -- the product
+  oracle/_build/libcg_oracle.so             plain-C CPU restatement (test/bench checker)    -- oracle/
+  tests/host_emul/libcg_emul.so             device code compiled for the host, 1-thread shim -- tests only
+"""
+import os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "coulombgas_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "coulombgas_amd", "lib")
+HIP_LIB = os.path.join(LIBDIR, "libcoulombgas_hip.so")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def hip_sources():
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "coulombgas.h")]
+
+
+def build_hip(force=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    if force or _newer(HIP_LIB, hip_sources()):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
+              "-o", HIP_LIB, os.path.join(CSRC, "cg_hip.hip"), "-ldl"])
+    return HIP_LIB
+
+
+def build_emul(force=False):
+    src = os.path.join(ROOT, "tests", "host_emul", "cg_emul.cpp")
+    out = os.path.join(ROOT, "tests", "host_emul", "libcg_emul.so")
+    if force or _newer(out, hip_sources() + [src]):
+        _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src])
+    return out
+
+
+def build_oracle(force=False):
+    src = os.path.join(ROOT, "oracle", "cg_oracle.c")
+    outdir = os.path.join(ROOT, "oracle", "_build")
+    out = os.path.join(outdir, "libcg_oracle.so")
+    if not os.path.exists(src):
+        return None
+    os.makedirs(outdir, exist_ok=True)
+    if force or _newer(out, [src]):
+        _run(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", "-o", out, src, "-lm"])
+    return out
+
+
+if __name__ == "__main__":
+    f = "--force" in sys.argv
+    build_hip(f); build_emul(f); build_oracle(f)

@@ -1,0 +1,106 @@
+"""Batch-axis mean over the GPUs of a node: the counterpart of jax.lax.pmean(axis_name="p")
+(src/MCMC.py:39, src/VMC.py:46-53,63,72, main.py:280).  One process per GPU.
+
+  NullComm        world size 1 (identity)
+  RcclComm        RCCL all-reduce over xGMI through the C-ABI (cg_allreduce_mean); the 128-byte unique id is
+                  exchanged through torch.distributed's store/broadcast (plumbing only)
+  TorchDistComm   torch.distributed all_reduce on host tensors (gloo) -- used by the CPU tests of the
+                  multi-process host logic
+"""
+import ctypes as C
+import numpy as np
+
+
+class NullComm:
+    rank, world = 0, 1
+
+    def pmean(self, a):
+        return a
+
+    def close(self):
+        pass
+
+
+class TorchDistComm:
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def pmean(self, a):
+        import torch
+        t = torch.from_numpy(np.array(a, dtype=np.float64, ndmin=1, copy=True))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        out = (t / self.world).numpy()
+        return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
+
+    def close(self):
+        pass
+
+
+class RcclComm:
+    """RCCL communicator bound to an Engine's device/stream."""
+
+    def __init__(self, engine, rank, world, unique_id=None, exchange=None):
+        from ._lib import lib, check
+        self.engine, self.rank, self.world = engine, rank, world
+        uid = (C.c_char * 128)()
+        if unique_id is None:
+            if rank == 0:
+                check(lib().cg_comm_unique_id(uid), None)
+            if exchange is None:
+                exchange = _torch_broadcast_bytes
+            raw = exchange(bytes(uid.raw) if rank == 0 else None)
+            uid = (C.c_char * 128).from_buffer_copy(raw)
+        else:
+            uid = (C.c_char * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        check(lib().cg_comm_create(C.byref(h), engine._ctx, rank, world, uid), None)
+        self._h = h
+        self._buf = None
+
+    def pmean(self, a):
+        from ._lib import lib, check
+        arr = np.array(a, dtype=np.float64, ndmin=1, copy=True)
+        flat = np.ascontiguousarray(arr.ravel())
+        if self._buf is None or self._buf.nbytes < flat.nbytes:
+            self._buf = self.engine.alloc((max(flat.size, 16),))
+        check(lib().cg_memcpy_h2d(self.engine._ctx, self._buf.ptr, flat.ctypes.data_as(C.c_void_p), flat.nbytes), self.engine._ctx)
+        check(lib().cg_allreduce_mean(self._h, self._buf.ptr, flat.size), self.engine._ctx)
+        check(lib().cg_memcpy_d2h(self.engine._ctx, flat.ctypes.data_as(C.c_void_p), self._buf.ptr, flat.nbytes), self.engine._ctx)
+        out = flat.reshape(arr.shape)
+        return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
+
+    def pmean_dev(self, buf, count):
+        from ._lib import lib, check
+        check(lib().cg_allreduce_mean(self._h, buf.ptr, int(count)), self.engine._ctx)
+
+    def close(self):
+        if self._h is not None:
+            from ._lib import lib
+            lib().cg_comm_destroy(self._h)
+            self._h = None
+
+
+def _torch_broadcast_bytes(payload):
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(128, dtype=torch.uint8)
+    if dist.get_rank() == 0:
+        t = torch.tensor(list(payload), dtype=torch.uint8)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
+
+
+_COMM = NullComm()
+
+
+def set_comm(comm):
+    global _COMM
+    _COMM = comm if comm is not None else NullComm()
+
+
+def get_comm():
+    return _COMM

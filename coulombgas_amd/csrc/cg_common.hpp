@@ -73,3 +73,18 @@ CG_DEVI CgCplx cinv(CgCplx a) {
         return {r * d, -d};
     }
 }
+
+// Deterministic (fixed-order) workgroup sum through LDS scratch of nthr doubles.
+CG_DEVI double cg_block_sum(const CgBlk& b, double v, double* scratch) {
+    scratch[b.tid] = v;
+    b.sync();
+    int s = 1;
+    while (s < b.nthr) s <<= 1;
+    for (s >>= 1; s > 0; s >>= 1) {
+        if (b.tid < s && b.tid + s < b.nthr) scratch[b.tid] += scratch[b.tid + s];
+        b.sync();
+    }
+    const double r = scratch[0];
+    b.sync();
+    return r;
+}

@@ -1,0 +1,822 @@
+// cg_hip.hip -- gfx950 kernels + the C-ABI of include/coulombgas.h.
+// One workgroup per walker; all per-walker intermediates live in LDS (layout: cg_fast_layout).
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+
+#include "../../include/coulombgas.h"
+#include "cg_common.hpp"
+#include "cg_linalg.hpp"
+#include "cg_flow_fast.hpp"
+#include "cg_dispatch.hpp"
+#include "cg_rng.hpp"
+#include "cg_ewald.hpp"
+#include "cg_derivs.hpp"
+
+// ------------------------------------------------------------------------------------------
+// device-side model descriptor (passed by value to every kernel)
+// ------------------------------------------------------------------------------------------
+struct CgDev {
+    const double* theta;   // P
+    const double* spk;     // M x D, already multiplied by 2 pi / L
+    int n;
+    double L;
+    CgFastLds lay;
+};
+
+enum { CG_MODE_LOGPSI = 0, CG_MODE_FLOW = 1, CG_MODE_JAC = 2 };
+
+template <int D, int HS, int HT, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+                         double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
+                         double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out) {
+    using F = CgFast<D, HS, HT>;
+    extern __shared__ double lds[];
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const int n = m.n, N = n * D;
+    double* xs = lds + m.lay.total;
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        for (int e = b.tid; e < N; e += b.nthr) xs[e] = x[(size_t)w * N + e];
+        b.sync();
+        if (mode == CG_MODE_LOGPSI) {
+            double re, im, h;
+            F::logpsi(b, m.theta, xs, m.spk, sidx + (size_t)w * n, n, m.L, lds, m.lay, re, im, h);
+            if (b.tid == 0) {
+                if (logphi) { logphi[2 * w] = re; logphi[2 * w + 1] = im; }
+                if (hld) hld[w] = h;
+                if (logpsi_out) { logpsi_out[2 * w] = re + h; logpsi_out[2 * w + 1] = im; }
+                if (logp_out) logp_out[w] = 2.0 * (re + h);
+            }
+        } else {
+            F::primal(b, m.theta, xs, n, m.L, lds, m.lay);
+            if (z_out)
+                for (int e = b.tid; e < N; e += b.nthr) z_out[(size_t)w * N + e] = lds[m.lay.z + e];
+            if (mode == CG_MODE_JAC) {
+                F::jacobian(b, m.theta, n, m.L, lds, m.lay);
+                for (int e = b.tid; e < N * N; e += b.nthr) J_out[(size_t)w * N * N + e] = lds[m.lay.J + e];
+            }
+        }
+        b.sync();
+    }
+}
+
+// Batched Metropolis chain: src/MCMC.py:22-39.  One workgroup owns one walker for all mc_steps;
+// x is read once and written once, the proposal/accept state never leaves the CU.
+template <int D, int HS, int HT, int MAXT>
+__global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
+                       uint64_t seed, uint64_t walker_offset, const double* __restrict__ noise,
+                       const double* __restrict__ unif, double* __restrict__ logp_out,
+                       unsigned long long* __restrict__ n_accept) {
+    using F = CgFast<D, HS, HT>;
+    extern __shared__ double lds[];
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const int n = m.n, N = n * D;
+    double* xc = lds + m.lay.total;          // current configuration
+    double* xp = xc + ((N + 1) & ~1);        // proposal
+    int* flag = (int*)(xp + ((N + 1) & ~1));
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        const int* si = sidx + (size_t)w * n;
+        for (int e = b.tid; e < N; e += b.nthr) xc[e] = x[(size_t)w * N + e];
+        b.sync();
+        double re, im, h;
+        F::logpsi(b, m.theta, xc, m.spk, si, n, m.L, lds, m.lay, re, im, h);
+        double logp = 2.0 * (re + h);
+        unsigned int nacc = 0;
+        for (int s = 0; s < steps; ++s) {
+            for (int e = b.tid; e < N; e += b.nthr) {
+                const double g = noise ? noise[((size_t)s * B + w) * N + e]
+                                       : cg_philox_normal(seed, walker_offset + w, (uint32_t)s, (uint32_t)e);
+                xp[e] = xc[e] + stddev * g;
+            }
+            b.sync();
+            F::logpsi(b, m.theta, xp, m.spk, si, n, m.L, lds, m.lay, re, im, h);
+            const double lp = 2.0 * (re + h);
+            if (b.tid == 0) {
+                const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
+                const double ratio = exp(lp - logp);
+                *flag = (u < ratio) ? 1 : 0;          // NaN -> reject, +inf -> accept (src/MCMC.py:28-29)
+            }
+            b.sync();
+            const int acc = *flag;
+            if (acc) {
+                for (int e = b.tid; e < N; e += b.nthr) xc[e] = xp[e];
+                logp = lp; ++nacc;
+            }
+            b.sync();
+        }
+        for (int e = b.tid; e < N; e += b.nthr) x[(size_t)w * N + e] = xc[e];
+        if (b.tid == 0) {
+            if (logp_out) logp_out[w] = logp;
+            if (n_accept && nacc) atomicAdd(n_accept, (unsigned long long)nacc);
+        }
+        b.sync();
+    }
+}
+
+template <int D>
+__global__ void k_ewald(const double* __restrict__ x, int B, int n, double L, double kappa, double rs,
+                        const int* __restrict__ G, const double* __restrict__ gk, int nG, int Gmax, double g0,
+                        double* __restrict__ V) {
+    extern __shared__ double lds[];
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const int N = n * D;
+    double* xs = lds;
+    double* rest = lds + ((N + 1) & ~1);
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        for (int e = b.tid; e < N; e += b.nthr) xs[e] = x[(size_t)w * N + e];
+        b.sync();
+        const double v = cg_ewald_walker<D>(b, xs, n, L, kappa, rs, G, gk, nG, Gmax, g0, rest);
+        if (b.tid == 0) V[w] = v;
+        b.sync();
+    }
+}
+
+__global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { const double v = x[i]; x[i] = v - L * floor(v / L); }
+}
+
+// grad / Laplacian of log Psi w.r.t. x (cg_derivs.hpp); per-walker workspace in HBM.
+template <int D, int HS, int HT>
+__global__ void k_grad_lap(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+                           const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
+                           double* __restrict__ ws, size_t ws_per_walker) {
+    extern __shared__ double lds[];
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const int n = m.n, N = n * D;
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        CgDerivs<D, HS, HT>::grad_laplacian(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L, mode,
+                                            v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
+                                            ws + (size_t)blockIdx.x * ws_per_walker, lds);
+        b.sync();
+    }
+}
+
+template <int D, int HS, int HT>
+__global__ void k_param_vjp(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+                            const double* __restrict__ w_re, const double* __restrict__ w_im,
+                            double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
+                            double* __restrict__ ws, size_t ws_per_walker) {
+    extern __shared__ double lds[];
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const int n = m.n, N = n * D;
+    constexpr int P = CgFast<D, HS, HT>::NPARAM;
+    double* gacc = partial ? partial + (size_t)blockIdx.x * P : nullptr;
+    if (gacc) for (int e = b.tid; e < P; e += b.nthr) gacc[e] = 0.0;
+    b.sync();
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        CgDerivs<D, HS, HT>::param_vjp(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L,
+                                       w_re ? w_re[w] : 1.0, w_im ? w_im[w] : 0.0, gacc,
+                                       score ? score + (size_t)w * P * 2 : nullptr,
+                                       ws + (size_t)blockIdx.x * ws_per_walker, lds);
+        b.sync();
+    }
+}
+
+// deterministic second-stage reduction of per-workgroup partial gradients: out[p] = sum_g partial[g][p]
+__global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int P, double* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += partial[(size_t)r * P + p];
+    out[p] = a;
+}
+
+__global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) buf[i] *= s;
+}
+
+
+// fp64 peak micro-benchmarks (roofline denominators for bench.py; /opt/skills/guides has no f64 row)
+__global__ void __launch_bounds__(256) k_peak_fma64(double* out, int iters, double a, double b) {
+    double v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (double)(threadIdx.x + i);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = fma(v[i], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    if (s == 12345.678) out[0] = s;
+}
+typedef double cg_d4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_peak_mfma64(double* out, int iters, double a, double b) {
+    cg_d4 c0 = {0, 0, 0, 0}, c1 = {1, 1, 1, 1}, c2 = {2, 2, 2, 2}, c3 = {3, 3, 3, 3};
+    const double av = a + threadIdx.x, bv = b - threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c3, 0, 0, 0);
+    }
+    double s = c0[0] + c1[1] + c2[2] + c3[3];
+    if (s == 12345.678) out[0] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+struct Chunk { void* p; size_t cap; };
+
+struct cg_ctx {
+    int device = 0, n = 0, dim = 0, depth = 0, hs = 0, ht = 0, M = 0, P = 0;
+    double L = 0;
+    bool fast = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* d_theta = nullptr;
+    double* d_spk = nullptr;
+    bool have_theta = false;
+    // ewald
+    bool have_ewald = false;
+    double kappa = 0, rs = 0, g0 = 0;
+    int nG = 0, Gmax = 0;
+    int* d_G = nullptr;
+    double* d_gk = nullptr;
+    int ptr_mode = CG_PTR_HOST;
+    int block_threads = 0;
+    int cu_count = 256;
+    CgFastLds lay;
+    unsigned long long* d_accept = nullptr;
+    // staging arena for host-pointer mode + internal workspaces
+    std::vector<Chunk> chunks;
+    size_t cur = 0, off = 0;
+    // persistent workspace (derivative kernels)
+    void* ws = nullptr; size_t ws_cap = 0;
+    std::string err;
+};
+
+#define CG_FAIL(ctx, code, ...)                                         \
+    do {                                                                \
+        char _b[512]; snprintf(_b, sizeof(_b), __VA_ARGS__);            \
+        if (ctx) (ctx)->err = _b;                                       \
+        g_last_error = _b;                                              \
+        return (code);                                                  \
+    } while (0)
+
+#define CG_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) CG_FAIL(ctx, CG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+static int arena_reset(cg_ctx* c) {
+    if (c->chunks.size() > 1) {
+        size_t tot = 0;
+        for (auto& ch : c->chunks) { tot += ch.cap; (void)hipFree(ch.p); }
+        c->chunks.clear();
+        void* p = nullptr;
+        if (hipMalloc(&p, tot) != hipSuccess) return CG_ERR_HIP;
+        c->chunks.push_back({p, tot});
+    }
+    c->cur = 0; c->off = 0;
+    return CG_OK;
+}
+static void* arena_take(cg_ctx* c, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    while (c->cur < c->chunks.size()) {
+        if (c->off + bytes <= c->chunks[c->cur].cap) { void* p = (char*)c->chunks[c->cur].p + c->off; c->off += bytes; return p; }
+        ++c->cur; c->off = 0;
+    }
+    size_t cap = std::max(bytes, (size_t)(c->chunks.empty() ? (1u << 20) : 2 * c->chunks.back().cap));
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) return nullptr;
+    c->chunks.push_back({p, cap});
+    c->cur = c->chunks.size() - 1; c->off = bytes;
+    return p;
+}
+
+// An argument that is an input and/or output array in either pointer mode.
+struct Arg {
+    void* user; void* dev; size_t bytes; bool in, out;
+};
+static int stage(cg_ctx* c, Arg& a) {
+    if (!a.user) { a.dev = nullptr; return CG_OK; }
+    if (c->ptr_mode == CG_PTR_DEVICE) { a.dev = a.user; return CG_OK; }
+    a.dev = arena_take(c, a.bytes);
+    if (!a.dev) CG_FAIL(c, CG_ERR_HIP, "device staging allocation of %zu bytes failed", a.bytes);
+    if (a.in) CG_HIP(c, hipMemcpyAsync(a.dev, a.user, a.bytes, hipMemcpyHostToDevice, c->stream));
+    return CG_OK;
+}
+static int unstage(cg_ctx* c, Arg& a) {
+    if (!a.user || c->ptr_mode == CG_PTR_DEVICE || !a.out) return CG_OK;
+    CG_HIP(c, hipMemcpyAsync(a.user, a.dev, a.bytes, hipMemcpyDeviceToHost, c->stream));
+    return CG_OK;
+}
+static int finish(cg_ctx* c) {
+    CG_HIP(c, hipGetLastError());
+    if (c->ptr_mode == CG_PTR_HOST) CG_HIP(c, hipStreamSynchronize(c->stream));
+    return CG_OK;
+}
+
+static int auto_threads(int n) {
+    if (n <= 16) return 64;
+    if (n <= 24) return 128;
+    if (n <= 40) return 256;
+    if (n <= 64) return 512;
+    return 1024;
+}
+static int threads_of(const cg_ctx* c) { return c->block_threads > 0 ? c->block_threads : auto_threads(c->n); }
+
+static CgDev make_dev(const cg_ctx* c) {
+    CgDev m; m.theta = c->d_theta; m.spk = c->d_spk; m.n = c->n; m.L = c->L; m.lay = c->lay;
+    return m;
+}
+
+template <class K>
+static int set_lds(cg_ctx* c, K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "workgroup needs %zu bytes of LDS (> 160 KiB): n too large for the LDS-resident path", bytes);
+    if (bytes > 48 * 1024) CG_HIP(c, hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return CG_OK;
+}
+
+extern "C" {
+
+const char* cg_last_error(const cg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, int tpsize, double L,
+              const double* sp_indices, int M) {
+    if (!out) CG_FAIL((cg_ctx*)nullptr, CG_ERR_ARG, "cg_create: out is NULL");
+    *out = nullptr;
+    if (n < 1 || (dim != 2 && dim != 3) || depth < 2 || spsize < 1 || tpsize < 1 || !(L > 0) || !sp_indices || M < n)
+        CG_FAIL((cg_ctx*)nullptr, CG_ERR_ARG, "cg_create: bad argument (n=%d dim=%d depth=%d spsize=%d tpsize=%d L=%g M=%d); depth >= 2 "
+                "(src/flow.py:52 is ill-formed for depth 1), dim in {2,3}, M >= n", n, dim, depth, spsize, tpsize, L, M);
+    if (!cg_fast_supported(depth, dim, spsize, tpsize))
+        CG_FAIL((cg_ctx*)nullptr, CG_ERR_UNSUPPORTED, "cg_create: no kernel instantiation for depth=%d dim=%d spsize=%d tpsize=%d "
+                "(built: depth 2 with (dim,spsize,tpsize) in cg_dispatch.hpp)", depth, dim, spsize, tpsize);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) CG_FAIL((cg_ctx*)nullptr, CG_ERR_HIP, "cg_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) CG_FAIL((cg_ctx*)nullptr, CG_ERR_ARG, "cg_create: device %d out of range [0,%d)", device, ndev);
+    cg_ctx* c = new cg_ctx();
+    c->device = device; c->n = n; c->dim = dim; c->depth = depth; c->hs = spsize; c->ht = tpsize; c->M = M; c->L = L;
+    c->fast = true;
+#define CG_X(D, HS, HT) if (dim == D && spsize == HS && tpsize == HT) c->P = CgFast<D, HS, HT>::NPARAM;
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    c->lay = cg_fast_layout(n, dim, spsize, tpsize, true);
+    auto fail = [&](const char* what, hipError_t err) {
+        g_last_error = std::string("cg_create: ") + what + ": " + hipGetErrorString(err);
+        delete c; return CG_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->cu_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipMalloc((void**)&c->d_theta, sizeof(double) * c->P)) != hipSuccess) return fail("hipMalloc theta", e);
+    if ((e = hipMalloc((void**)&c->d_spk, sizeof(double) * (size_t)M * dim)) != hipSuccess) return fail("hipMalloc orbitals", e);
+    if ((e = hipMalloc((void**)&c->d_accept, sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
+    std::vector<double> spk((size_t)M * dim);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);     // src/slater.py:14
+    if ((e = hipMemcpy(c->d_spk, spk.data(), sizeof(double) * spk.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy orbitals", e);
+    if ((e = hipMemset(c->d_accept, 0, sizeof(unsigned long long))) != hipSuccess) return fail("hipMemset", e);
+    *out = c;
+    return CG_OK;
+}
+
+void cg_destroy(cg_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& ch : c->chunks) (void)hipFree(ch.p);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_theta) (void)hipFree(c->d_theta);
+    if (c->d_spk) (void)hipFree(c->d_spk);
+    if (c->d_G) (void)hipFree(c->d_G);
+    if (c->d_gk) (void)hipFree(c->d_gk);
+    if (c->d_accept) (void)hipFree(c->d_accept);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int cg_set_pointer_mode(cg_ctx* c, int mode) {
+    if (!c) return CG_ERR_ARG;
+    if (mode != CG_PTR_HOST && mode != CG_PTR_DEVICE) CG_FAIL(c, CG_ERR_ARG, "cg_set_pointer_mode: mode %d", mode);
+    c->ptr_mode = mode; return CG_OK;
+}
+int cg_sync(cg_ctx* c) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    return CG_OK;
+}
+int cg_num_params(const cg_ctx* c) { return c ? c->P : CG_ERR_ARG; }
+
+int cg_set_flow_params(cg_ctx* c, const double* theta) {
+    if (!c || !theta) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipMemcpyAsync(c->d_theta, theta, sizeof(double) * c->P, hipMemcpyHostToDevice, c->stream));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_theta = true;
+    return CG_OK;
+}
+
+int cg_set_ewald(cg_ctx* c, double kappa, const int64_t* G, int nG, double rs) {
+    if (!c || !G || nG < 1 || !(kappa > 0)) CG_FAIL(c, CG_ERR_ARG, "cg_set_ewald: bad argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    const int D = c->dim;
+    std::vector<int> g32((size_t)nG * D);
+    std::vector<double> gk(nG);
+    int gmax = 0;
+    for (int g = 0; g < nG; ++g) {
+        double g2 = 0;
+        for (int a = 0; a < D; ++a) {
+            int64_t v = G[(size_t)g * D + a];
+            if (v > 4096 || v < -4096) CG_FAIL(c, CG_ERR_ARG, "cg_set_ewald: |G| component %lld too large", (long long)v);
+            g32[(size_t)g * D + a] = (int)v; gmax = std::max(gmax, (int)std::llabs(v)); g2 += (double)v * (double)v;
+        }
+        if (g2 == 0) CG_FAIL(c, CG_ERR_ARG, "cg_set_ewald: G = 0 must not be in the list (src/potential.py:16)");
+        const double gn = std::sqrt(g2);
+        // src/potential.py:54-59
+        gk[g] = (D == 3) ? std::exp(-CG_PI * CG_PI * g2 / (kappa * kappa)) / (CG_PI * g2) : std::erfc(CG_PI * gn / kappa) / gn;
+    }
+    c->g0 = (D == 3) ? -CG_PI / (kappa * kappa) : -2.0 * std::sqrt(CG_PI) / kappa;
+    if (c->d_G) { (void)hipFree(c->d_G); c->d_G = nullptr; }
+    if (c->d_gk) { (void)hipFree(c->d_gk); c->d_gk = nullptr; }
+    CG_HIP(c, hipMalloc((void**)&c->d_G, sizeof(int) * g32.size()));
+    CG_HIP(c, hipMalloc((void**)&c->d_gk, sizeof(double) * nG));
+    CG_HIP(c, hipMemcpy(c->d_G, g32.data(), sizeof(int) * g32.size(), hipMemcpyHostToDevice));
+    CG_HIP(c, hipMemcpy(c->d_gk, gk.data(), sizeof(double) * nG, hipMemcpyHostToDevice));
+    c->kappa = kappa; c->rs = rs; c->nG = nG; c->Gmax = gmax; c->have_ewald = true;
+    return CG_OK;
+}
+
+int cg_dev_alloc(cg_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipMalloc(dptr, bytes ? bytes : 8));
+    return CG_OK;
+}
+int cg_dev_free(cg_ctx* c, void* dptr) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    CG_HIP(c, hipFree(dptr));
+    return CG_OK;
+}
+int cg_memcpy_h2d(cg_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    return CG_OK;
+}
+int cg_memcpy_d2h(cg_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    return CG_OK;
+}
+int cg_memset(cg_ctx* c, void* dst, int value, size_t bytes) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return CG_OK;
+}
+int cg_timer_start(cg_ctx* c) {
+    if (!c) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipEventRecord(c->ev0, c->stream));
+    return CG_OK;
+}
+int cg_timer_stop(cg_ctx* c, float* ms) {
+    if (!c || !ms) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    CG_HIP(c, hipEventRecord(c->ev1, c->stream));
+    CG_HIP(c, hipEventSynchronize(c->ev1));
+    CG_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return CG_OK;
+}
+int cg_set_block_threads(cg_ctx* c, int threads) {
+    if (!c) return CG_ERR_ARG;
+    if (threads != 0 && (threads < 64 || threads > 1024 || threads % 64)) CG_FAIL(c, CG_ERR_ARG, "cg_set_block_threads: %d is not 0 or a multiple of 64 in [64,1024]", threads);
+    c->block_threads = threads; return CG_OK;
+}
+int cg_get_launch_info(cg_ctx* c, int64_t* info) {
+    if (!c || !info) return CG_ERR_ARG;
+    const int N = c->n * c->dim;
+    info[0] = threads_of(c);
+    info[1] = (int64_t)sizeof(double) * (c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    info[2] = c->cu_count; info[3] = c->P; info[4] = c->fast ? 1 : 0; info[5] = info[6] = info[7] = 0;
+    return CG_OK;
+}
+
+static int check_ready(cg_ctx* c, const char* fn, int B) {
+    if (!c) return CG_ERR_ARG;
+    if (B < 0) CG_FAIL(c, CG_ERR_ARG, "%s: negative batch", fn);
+    if (!c->have_theta) CG_FAIL(c, CG_ERR_STATE, "%s: cg_set_flow_params has not been called", fn);
+    CG_HIP(c, hipSetDevice(c->device));
+    return CG_OK;
+}
+
+static int run_logpsi(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, int mode,
+                      double* logphi, double* hld, double* logpsi_out, double* logp_out, double* z_out, double* J_out) {
+    int rc = check_ready(c, fn, B); if (rc) return rc;
+    if (B == 0) return CG_OK;
+    if (!x || (mode == CG_MODE_LOGPSI && !sidx)) CG_FAIL(c, CG_ERR_ARG, "%s: NULL input", fn);
+    const int n = c->n, N = n * c->dim;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "%s: arena", fn);
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg a1{logphi, nullptr, sizeof(double) * 2 * (size_t)B, false, true};
+    Arg a2{hld, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg a3{logpsi_out, nullptr, sizeof(double) * 2 * (size_t)B, false, true};
+    Arg a4{logp_out, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg a5{z_out, nullptr, sizeof(double) * (size_t)B * N, false, true};
+    Arg a6{J_out, nullptr, sizeof(double) * (size_t)B * N * N, false, true};
+    Arg* all[] = {&ax, &as, &a1, &a2, &a3, &a4, &a5, &a6};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int nt = threads_of(c);
+    const size_t lds = sizeof(double) * (c->lay.total + ((N + 1) & ~1));
+    const CgDev m = make_dev(c);
+    bool launched = false;
+#define CG_X(D, HS, HT)                                                                                              \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
+        if (nt <= 256) {                                                                                             \
+            if ((rc = set_lds(c, k_logpsi<D, HS, HT, 256>, lds))) return rc;                                         \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
+                               (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
+        } else {                                                                                                     \
+            if ((rc = set_lds(c, k_logpsi<D, HS, HT, 1024>, lds))) return rc;                                        \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
+                               (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
+        }                                                                                                            \
+        launched = true;                                                                                             \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+
+int cg_flow_forward(cg_ctx* c, const double* x, int B, double* z) {
+    if (c && !z) CG_FAIL(c, CG_ERR_ARG, "cg_flow_forward: z is NULL");
+    return run_logpsi(c, "cg_flow_forward", x, nullptr, B, CG_MODE_FLOW, nullptr, nullptr, nullptr, nullptr, z, nullptr);
+}
+int cg_flow_jacobian(cg_ctx* c, const double* x, int B, double* J) {
+    if (c && !J) CG_FAIL(c, CG_ERR_ARG, "cg_flow_jacobian: J is NULL");
+    return run_logpsi(c, "cg_flow_jacobian", x, nullptr, B, CG_MODE_JAC, nullptr, nullptr, nullptr, nullptr, nullptr, J);
+}
+int cg_logpsi(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* out) {
+    if (c && !out) CG_FAIL(c, CG_ERR_ARG, "cg_logpsi: out is NULL");
+    return run_logpsi(c, "cg_logpsi", x, sidx, B, CG_MODE_LOGPSI, nullptr, nullptr, out, nullptr, nullptr, nullptr);
+}
+int cg_logphi_logjacdet(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* logphi, double* hld) {
+    return run_logpsi(c, "cg_logphi_logjacdet", x, sidx, B, CG_MODE_LOGPSI, logphi, hld, nullptr, nullptr, nullptr, nullptr);
+}
+int cg_logp(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* logp) {
+    if (c && !logp) CG_FAIL(c, CG_ERR_ARG, "cg_logp: logp is NULL");
+    return run_logpsi(c, "cg_logp", x, sidx, B, CG_MODE_LOGPSI, nullptr, nullptr, nullptr, logp, nullptr, nullptr);
+}
+
+int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, double mc_stddev, uint64_t seed,
+            uint64_t walker_offset, const double* noise, const double* unif, double* logp_out, int64_t* n_accept) {
+    int rc = check_ready(c, "cg_mcmc", B); if (rc) return rc;
+    if (mc_steps < 0) CG_FAIL(c, CG_ERR_ARG, "cg_mcmc: mc_steps < 0");
+    if ((noise == nullptr) != (unif == nullptr)) CG_FAIL(c, CG_ERR_ARG, "cg_mcmc: noise and unif must both be given or both be NULL");
+    if (n_accept) *n_accept = 0;
+    if (B == 0) return CG_OK;
+    if (!x || !sidx) CG_FAIL(c, CG_ERR_ARG, "cg_mcmc: NULL input");
+    const int n = c->n, N = n * c->dim;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_mcmc: arena");
+    Arg ax{x, nullptr, sizeof(double) * (size_t)B * N, true, true};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg an{(void*)noise, nullptr, sizeof(double) * (size_t)mc_steps * B * N, true, false};
+    Arg au{(void*)unif, nullptr, sizeof(double) * (size_t)mc_steps * B, true, false};
+    Arg al{logp_out, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg* all[] = {&ax, &as, &an, &au, &al};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    CG_HIP(c, hipMemsetAsync(c->d_accept, 0, sizeof(unsigned long long), c->stream));
+    const int nt = threads_of(c);
+    const size_t lds = sizeof(double) * (c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    const CgDev m = make_dev(c);
+    bool launched = false;
+#define CG_X(D, HS, HT)                                                                                             \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                  \
+        if (nt <= 256) {                                                                                            \
+            if ((rc = set_lds(c, k_mcmc<D, HS, HT, 256>, lds))) return rc;                                          \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (double*)ax.dev,     \
+                               (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
+                               (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
+        } else {                                                                                                    \
+            if ((rc = set_lds(c, k_mcmc<D, HS, HT, 1024>, lds))) return rc;                                         \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (double*)ax.dev,    \
+                               (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
+                               (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
+        }                                                                                                           \
+        launched = true;                                                                                            \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_mcmc: configuration not instantiated");
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    if ((rc = finish(c))) return rc;
+    if (n_accept) return cg_mcmc_accepts(c, n_accept);
+    return CG_OK;
+}
+
+int cg_mcmc_accepts(cg_ctx* c, int64_t* n_accept) {
+    if (!c || !n_accept) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    unsigned long long v = 0;
+    CG_HIP(c, hipMemcpyAsync(&v, c->d_accept, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    *n_accept = (int64_t)v;
+    return CG_OK;
+}
+
+int cg_wrap(cg_ctx* c, double* x, int B) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (B == 0) return CG_OK;
+    if (!x) CG_FAIL(c, CG_ERR_ARG, "cg_wrap: x is NULL");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_wrap: arena");
+    const size_t cnt = (size_t)B * c->n * c->dim;
+    Arg ax{x, nullptr, sizeof(double) * cnt, true, true};
+    if ((rc = stage(c, ax))) return rc;
+    hipLaunchKernelGGL(k_wrap, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, (double*)ax.dev, cnt, c->L);
+    if ((rc = unstage(c, ax))) return rc;
+    return finish(c);
+}
+
+int cg_ewald(cg_ctx* c, const double* x, int B, double* V) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (!c->have_ewald) CG_FAIL(c, CG_ERR_STATE, "cg_ewald: cg_set_ewald has not been called");
+    if (B == 0) return CG_OK;
+    if (!x || !V) CG_FAIL(c, CG_ERR_ARG, "cg_ewald: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_ewald: arena");
+    const int n = c->n, D = c->dim, N = n * D;
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg av{V, nullptr, sizeof(double) * (size_t)B, false, true};
+    if ((rc = stage(c, ax)) || (rc = stage(c, av))) return rc;
+    const int nt = 256;
+    const size_t lds = sizeof(double) * (((N + 1) & ~1) + (size_t)N * (c->Gmax + 1) * 2 + nt);
+    if (D == 2) {
+        if ((rc = set_lds(c, k_ewald<2>, lds))) return rc;
+        hipLaunchKernelGGL((k_ewald<2>), dim3(B), dim3(nt), lds, c->stream, (const double*)ax.dev, B, n, c->L, c->kappa,
+                           c->rs, (const int*)c->d_G, (const double*)c->d_gk, c->nG, c->Gmax, c->g0, (double*)av.dev);
+    } else {
+        if ((rc = set_lds(c, k_ewald<3>, lds))) return rc;
+        hipLaunchKernelGGL((k_ewald<3>), dim3(B), dim3(nt), lds, c->stream, (const double*)ax.dev, B, n, c->L, c->kappa,
+                           c->rs, (const int*)c->d_G, (const double*)c->d_gk, c->nG, c->Gmax, c->g0, (double*)av.dev);
+    }
+    if ((rc = unstage(c, av))) return rc;
+    return finish(c);
+}
+
+static int ensure_ws(cg_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_cap) return CG_OK;
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
+    CG_HIP(c, hipMalloc(&c->ws, bytes));
+    c->ws_cap = bytes;
+    return CG_OK;
+}
+
+int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, int mode, const double* v,
+                      double* grad, double* lap) {
+    int rc = check_ready(c, "cg_grad_laplacian", B); if (rc) return rc;
+    if (mode < 0 || mode > 2) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: mode %d", mode);
+    if (mode != CG_LAP_EXACT && !v) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: Hutchinson modes need v");
+    if (B == 0) return CG_OK;
+    if (!x || !sidx || !grad || !lap) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: NULL argument");
+    const int n = c->n, N = n * c->dim;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_grad_laplacian: arena");
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg av{(void*)v, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg ag{grad, nullptr, sizeof(double) * (size_t)B * N * 2, false, true};
+    Arg al{lap, nullptr, sizeof(double) * (size_t)B * 2, false, true};
+    Arg* all[] = {&ax, &as, &av, &ag, &al};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int nt = std::max(threads_of(c), 256);
+    const int grid = std::min(B, c->cu_count * 4);
+    const CgDev m = make_dev(c);
+    bool launched = false;
+#define CG_X(D, HS, HT)                                                                                              \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
+        const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                      \
+        const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                \
+        if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                            \
+        if ((rc = set_lds(c, k_grad_lap<D, HS, HT>, lds))) return rc;                                               \
+        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+                           (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev,    \
+                           (double*)c->ws, wsw);                                                                    \
+        launched = true;                                                                                            \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_grad_laplacian: configuration not instantiated");
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+
+static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
+                   const double* w_im, double* g_theta, double* score) {
+    int rc = check_ready(c, fn, B); if (rc) return rc;
+    const int n = c->n, N = n * c->dim, P = c->P;
+    if (B == 0) {
+        if (g_theta && c->ptr_mode == CG_PTR_HOST) memset(g_theta, 0, sizeof(double) * P);
+        else if (g_theta) CG_HIP(c, hipMemsetAsync(g_theta, 0, sizeof(double) * P, c->stream));
+        return CG_OK;
+    }
+    if (!x || !sidx) CG_FAIL(c, CG_ERR_ARG, "%s: NULL argument", fn);
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "%s: arena", fn);
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg awr{(void*)w_re, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg awi{(void*)w_im, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
+    Arg asc{score, nullptr, sizeof(double) * (size_t)B * P * 2, false, true};
+    Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int nt = std::max(threads_of(c), 256);
+    const int grid = std::min(B, c->cu_count * 4);
+    double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
+    if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
+    const CgDev m = make_dev(c);
+    bool launched = false;
+#define CG_X(D, HS, HT)                                                                                               \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
+        const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \
+        const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                 \
+        if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
+        if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
+        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+                           (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
+                           (double*)asc.dev, (double*)c->ws, wsw);                                                   \
+        launched = true;                                                                                             \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
+    if (g_theta)
+        hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+
+int cg_param_vjp(cg_ctx* c, const double* x, const int32_t* sidx, int B, const double* w_re, const double* w_im, double* g_theta) {
+    if (c && !g_theta) CG_FAIL(c, CG_ERR_ARG, "cg_param_vjp: g_theta is NULL");
+    if (c && (!w_re || !w_im) && B > 0) CG_FAIL(c, CG_ERR_ARG, "cg_param_vjp: weights are NULL");
+    return run_vjp(c, "cg_param_vjp", x, sidx, B, w_re, w_im, g_theta, nullptr);
+}
+int cg_quantum_score(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* score) {
+    if (c && !score) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_score: score is NULL");
+    return run_vjp(c, "cg_quantum_score", x, sidx, B, nullptr, nullptr, nullptr, score);
+}
+
+
+/* which: 0 = v_fma_f64 (VALU), 1 = v_mfma_f64_16x16x4_f64.  Returns achieved TFLOP/s (HIP-event timed). */
+int cg_microbench_fp64(cg_ctx* c, int which, double* tflops) {
+    if (!c || !tflops) return CG_ERR_ARG;
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_microbench_fp64: arena");
+    double* out = (double*)arena_take(c, 64);
+    const int blocks = c->cu_count * 8, iters = 20000;
+    for (int rep = 0; rep < 2; ++rep) {
+        CG_HIP(c, hipEventRecord(c->ev0, c->stream));
+        if (which == 0) hipLaunchKernelGGL(k_peak_fma64, dim3(blocks), dim3(256), 0, c->stream, out, iters, 0.999999, 1e-9);
+        else hipLaunchKernelGGL(k_peak_mfma64, dim3(blocks), dim3(256), 0, c->stream, out, iters, 0.5, 0.25);
+        CG_HIP(c, hipEventRecord(c->ev1, c->stream));
+        CG_HIP(c, hipEventSynchronize(c->ev1));
+    }
+    float ms = 0; CG_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const double flops = which == 0 ? (double)blocks * 256 * iters * 16 * 2 : (double)blocks * 4 /*waves*/ * iters * 4 * (16.0 * 16 * 4 * 2);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return CG_OK;
+}
+
+int cg_scale_dev(cg_ctx* c, double* buf, size_t count, double s) {
+    if (!c) return CG_ERR_ARG;
+    hipLaunchKernelGGL(k_scale, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, buf, count, s);
+    CG_HIP(c, hipGetLastError());
+    return CG_OK;
+}
+
+}  // extern "C"
+
+#include "cg_comm.inc"

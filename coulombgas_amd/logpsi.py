@@ -1,0 +1,124 @@
+"""Host-side mirror of src/logpsi.py: the factories keep the reference's names and signatures,
+the closures take / return numpy arrays of the reference's shapes; the arithmetic is
+libcoulombgas_hip.so (cg_logpsi, cg_logphi_logjacdet, cg_logp, cg_grad_laplacian, cg_quantum_score).
+
+The reference's closures are un-batched and get vmapped (src/logpsi.py:58,63,176,185); here every
+closure accepts x of shape (..., n, dim) with matching state_idx (..., n)."""
+import numpy as np
+from . import _lib
+
+
+class _WaveFn:
+    """What the reference's closures capture: (flow, sp_indices, L)."""
+
+    def __init__(self, flow, sp_indices, L):
+        self.flow, self.sp_indices, self.L = flow, np.ascontiguousarray(sp_indices, dtype=np.float64), float(L)
+
+    def engine(self, x, params):
+        n, dim = np.shape(x)[-2:]
+        eng = self.flow.engine(n, dim, self.sp_indices)
+        eng.set_params(self.flow.ravel(params, dim))
+        return eng
+
+
+def make_logpsi(flow, sp_indices, L):
+    """src/logpsi.py:7-33"""
+    wf = _WaveFn(flow, sp_indices, L)
+
+    def logpsi(x, params, state_idx):
+        return wf.engine(x, params).logpsi(x, state_idx)
+
+    logpsi.wf = wf
+    return logpsi
+
+
+def make_logphi_logjacdet(flow, sp_indices, L):
+    """src/logpsi.py:35-53"""
+    wf = _WaveFn(flow, sp_indices, L)
+
+    def logphi(x, params, state_idx):
+        return wf.engine(x, params).logphi_logjacdet(x, state_idx)[0]
+
+    def logjacdet(x, params):
+        n = np.shape(x)[-2]
+        lead = np.shape(x)[:-2]
+        sidx = np.broadcast_to(np.arange(n, dtype=np.int32), lead + (n,))
+        return wf.engine(x, params).logphi_logjacdet(x, sidx)[1]
+
+    logphi.wf = logjacdet.wf = wf
+    return logphi, logjacdet
+
+
+def make_logp(logpsi):
+    """src/logpsi.py:174-181.  The returned closure has `.bind(params, state_indices)` giving the
+    object `mcmc` needs to run the whole chain on the GPU."""
+    wf = logpsi.wf
+
+    def logp(x, params, state_idx):
+        return wf.engine(x, params).logp(x, state_idx)
+
+    class BoundLogp:
+        def __init__(self, params, state_indices):
+            self.wf, self.params, self.state_indices = wf, params, np.ascontiguousarray(state_indices, dtype=np.int32)
+
+        def __call__(self, x):
+            return logp(x, self.params, self.state_indices)
+
+    logp.wf = wf
+    logp.bind = BoundLogp
+    return logp
+
+
+def _draw_v(key, shape):
+    """Hutchinson probe (src/logpsi.py:110).  `key`: ndarray of x.shape (explicit probe, parity
+    mode), numpy Generator, or an int / SeedSequence seed."""
+    if isinstance(key, np.ndarray) and key.shape == tuple(shape):
+        return np.ascontiguousarray(key, dtype=np.float64)
+    rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+    return rng.standard_normal(shape)
+
+
+def make_logpsi_grad_laplacian(logpsi, forloop=True, hutchinson=False, logphi=None, logjacdet=None):
+    """src/logpsi.py:55-172.  `forloop` selects between two algebraically identical reference
+    variants (:86-100) and has no effect here."""
+    wf = logpsi.wf
+
+    def logpsi_vmapped(x, params, state_idx):
+        out = wf.engine(x, params).logpsi(x, state_idx)
+        return out[..., 0] + 1j * out[..., 1]
+
+    if not hutchinson:
+        mode = _lib.CG_LAP_EXACT
+    elif logphi is None and logjacdet is None:
+        mode = _lib.CG_LAP_HUTCHINSON
+    else:
+        mode = _lib.CG_LAP_HUTCHINSON_SPLIT
+
+    def logpsi_grad_laplacian(x, params, state_indices, key):
+        v = _draw_v(key, np.shape(x)) if hutchinson else None
+        return wf.engine(x, params).grad_laplacian(x, state_indices, mode, v)
+
+    logpsi_vmapped.wf = logpsi_grad_laplacian.wf = wf
+    logpsi_grad_laplacian.mode = mode
+    return logpsi_vmapped, logpsi_grad_laplacian
+
+
+def make_quantum_score(logpsi):
+    """src/logpsi.py:183-203: per-sample d log Psi / d theta, complex, as a params-shaped pytree with a
+    leading batch axis."""
+    wf = logpsi.wf
+
+    def quantum_score_fn(x, params, state_idx):
+        eng = wf.engine(x, params)
+        sc = eng.quantum_score(x, state_idx)              # (..., P) complex
+        dim = np.shape(x)[-1]
+        from .flow import ravel_order
+        out, off = {}, 0
+        for name, leaf, shp in ravel_order(wf.flow.depth, wf.flow.spsize, wf.flow.tpsize, dim):
+            sz = int(np.prod(shp))
+            out.setdefault(name, {})[leaf] = sc[..., off:off + sz].reshape(sc.shape[:-1] + shp)
+            off += sz
+        return out
+
+    quantum_score_fn.wf = wf
+    return quantum_score_fn

@@ -1,0 +1,148 @@
+/*
+ * coulombgas.h -- C-ABI of libcoulombgas_hip.so: the MI355X (gfx950) implementation of the
+ * data-parallel VMC inner loop of fermiflow/CoulombGas.
+ *
+ * The reference has no FFI layer: its boundary for this path is the set of Python factory
+ * functions re-exported by src/__init__.py:1-13 and called from main.py.  Each entry point
+ * below names the reference function it replaces (file:line relative to the reference tree);
+ * coulombgas_amd/ binds them with ctypes (see INTEGRATION.md for the stub a maintainer of the
+ * reference would add).
+ *
+ * Conventions
+ *   - plain C types only; every array is C-contiguous; complex = trailing (re, im) pair.
+ *   - all floating point is fp64; state indices are int32.
+ *   - return 0 = CG_OK, negative = error; cg_last_error() gives the message.  No exception,
+ *     longjmp or abort crosses the ABI.  NaN in -> NaN out.
+ *   - pointer mode (cg_set_pointer_mode): CG_PTR_HOST (default) = array arguments are host
+ *     pointers, the call stages them through device workspace and returns after the result
+ *     is back on the host; CG_PTR_DEVICE = array arguments are device pointers (cg_dev_alloc
+ *     or any hipMalloc'ed memory of the ctx's device), the call only enqueues work on the
+ *     ctx's stream and returns; cg_sync() waits.
+ *   - the caller owns every buffer it passes; the library never frees caller memory.
+ *   - a cg_ctx is not thread-safe: one host thread per ctx, or serialise calls.
+ *   - one cg_ctx per GPU and per (n, dim, flow architecture, orbital table).
+ */
+#ifndef COULOMBGAS_H
+#define COULOMBGAS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cg_ctx cg_ctx;
+typedef struct cg_comm cg_comm;
+
+enum { CG_OK = 0, CG_ERR_ARG = -1, CG_ERR_HIP = -2, CG_ERR_UNSUPPORTED = -3, CG_ERR_STATE = -4, CG_ERR_RCCL = -5 };
+enum { CG_PTR_HOST = 0, CG_PTR_DEVICE = 1 };
+enum { CG_LAP_EXACT = 0, CG_LAP_HUTCHINSON = 1, CG_LAP_HUTCHINSON_SPLIT = 2 };
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Builds the model the closures of main.py:152-164 capture: FermiNet(depth, spsize, tpsize, L)
+ * (src/flow.py:5-14), the twisted+sorted+reversed orbital table `sp_indices_twist`
+ * (main.py:79-90; M x dim doubles) and the box.  device = HIP device ordinal. */
+int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, int tpsize, double L,
+              const double* sp_indices, int M);
+void cg_destroy(cg_ctx* ctx);
+/* message of the last failing call on ctx (ctx == NULL: last failing cg_create / cg_comm_*). */
+const char* cg_last_error(const cg_ctx* ctx);
+int cg_set_pointer_mode(cg_ctx* ctx, int mode);
+int cg_sync(cg_ctx* ctx);
+/* number of flow parameters P = size of jax.flatten_util.ravel_pytree(params_flow) (main.py:159). */
+int cg_num_params(const cg_ctx* ctx);
+/* theta: HOST pointer, P doubles in ravel_pytree order of the Haiku tree (sorted module names,
+ * 'b' before 'w', w row-major (in,out)); replaces passing `params_flow` into every closure. */
+int cg_set_flow_params(cg_ctx* ctx, const double* theta);
+/* kappa, G (nG x dim integers, as returned by kpoints(), src/potential.py:7-17), rs.
+ * HOST pointers.  Replaces the (kappa, G, L, rs) arguments of make_loss (src/VMC.py:31). */
+int cg_set_ewald(cg_ctx* ctx, double kappa, const int64_t* G, int nG, double rs);
+
+/* device memory helpers so that host code needs no other GPU runtime */
+int cg_dev_alloc(cg_ctx* ctx, size_t bytes, void** dptr);
+int cg_dev_free(cg_ctx* ctx, void* dptr);
+int cg_memcpy_h2d(cg_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int cg_memcpy_d2h(cg_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int cg_memset(cg_ctx* ctx, void* dst_dev, int value, size_t bytes);
+/* HIP-event stopwatch on the ctx's stream (bench.py's kernel timing) */
+int cg_timer_start(cg_ctx* ctx);
+int cg_timer_stop(cg_ctx* ctx, float* ms);   /* records, synchronises, returns elapsed ms */
+/* tuning knob: threads per walker workgroup (0 = automatic from n) */
+int cg_set_block_threads(cg_ctx* ctx, int threads);
+/* fills info[0..7]: {threads per workgroup, LDS bytes per workgroup, device CU count, P, fast path (0/1), 0,0,0} */
+int cg_get_launch_info(cg_ctx* ctx, int64_t* info);
+
+/* diagnostics: measured fp64 peak of this GPU, which = 0: v_fma_f64 (VALU), 1: v_mfma_f64_16x16x4_f64;
+ * result in TFLOP/s.  bench.py uses it as the roofline denominator. */
+int cg_microbench_fp64(cg_ctx* ctx, int which, double* tflops);
+
+/* ---- wavefunction ---------------------------------------------------------------------- */
+
+/* z = flow.apply(params, None, x) batched: x, z (B,n,dim).   src/flow.py:39-55 */
+int cg_flow_forward(cg_ctx* ctx, const double* x, int B, double* z);
+/* Jacobian dz/dx per walker, J (B, n*dim, n*dim) row-major = jax.jacfwd(flow_flatten) of src/logpsi.py:27-28 */
+int cg_flow_jacobian(cg_ctx* ctx, const double* x, int B, double* J);
+/* out (B,2) = vmap(logpsi)(x, params, state_idx):  [Re log phi + 1/2 log|det J|, Im log phi].  src/logpsi.py:9-31 */
+int cg_logpsi(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* out);
+/* logphi (B,2), half_logdetJ (B): the two closures of make_logphi_logjacdet.  src/logpsi.py:35-53 */
+int cg_logphi_logjacdet(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* logphi, double* half_logdetJ);
+/* logp (B) = 2 Re log Psi.  src/logpsi.py:174-181 */
+int cg_logp(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* logp);
+
+/* ---- sampler --------------------------------------------------------------------------- */
+
+/* mcmc(logp_fn, x_init, key, mc_steps, mc_stddev) of src/MCMC.py:7-40 for logp = 2 Re logpsi(., params, state_idx).
+ *   x         (B,n,dim) in/out (NOT wrapped into the box; src/VMC.py:24 does that: cg_wrap)
+ *   noise     nullable (mc_steps,B,n,dim) standard normals; unif nullable (mc_steps,B) uniforms in [0,1):
+ *             when both are given they replace jax.random.normal / uniform of src/MCMC.py:26,29 (parity mode);
+ *             when NULL an in-kernel Philox4x32-10 stream keyed by (seed, walker_offset + walker, step) is used.
+ *   logp_out  nullable (B): final log-probabilities
+ *   n_accept  HOST pointer (both pointer modes), nullable: total accepted moves (the float accumulator of
+ *             src/MCMC.py:33,37 before the division at :39).  In CG_PTR_DEVICE mode a non-NULL n_accept
+ *             forces a stream synchronisation; use cg_mcmc_accepts() to read it later instead. */
+int cg_mcmc(cg_ctx* ctx, double* x, const int32_t* state_idx, int B, int mc_steps, double mc_stddev,
+            uint64_t seed, uint64_t walker_offset, const double* noise, const double* unif,
+            double* logp_out, int64_t* n_accept);
+/* accepted-move count of the most recent cg_mcmc on this ctx (synchronises the stream) */
+int cg_mcmc_accepts(cg_ctx* ctx, int64_t* n_accept);
+/* x -= L * floor(x / L).   src/VMC.py:24 */
+int cg_wrap(cg_ctx* ctx, double* x, int B);
+
+/* ---- potential --------------------------------------------------------------------------- */
+
+/* V (B) = potential_energy(x, kappa, G, L, rs) = 2 rs / L * psi(x / L, kappa, G)  (no Madelung term).
+ * src/potential.py:36-77 */
+int cg_ewald(cg_ctx* ctx, const double* x, int B, double* V);
+
+/* ---- local energy ingredients ------------------------------------------------------------ */
+
+/* grad (B,n,dim,2) complex, lap (B,2) complex of log Psi w.r.t. x:
+ *   mode CG_LAP_EXACT            make_logpsi_grad_laplacian(logpsi)            src/logpsi.py:63-106
+ *   mode CG_LAP_HUTCHINSON       ...(hutchinson=True)  v^T H v, v (B,n,dim)    src/logpsi.py:112-132
+ *   mode CG_LAP_HUTCHINSON_SPLIT ...(hutchinson=True, logphi, logjacdet)       src/logpsi.py:134-164
+ * v: nullable for CG_LAP_EXACT; replaces jax.random.normal(key, x.shape) of src/logpsi.py:110. */
+int cg_grad_laplacian(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, int mode,
+                      const double* v, double* grad, double* lap);
+
+/* g_theta (P) = sum_b [ w_re[b] * d/dtheta Re log Psi_b + w_im[b] * d/dtheta Im log Psi_b ]:
+ * the vector-Jacobian product jax.jacrev(quantum_lossfn) needs (src/VMC.py:69-76, main.py:278). */
+int cg_param_vjp(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B,
+                 const double* w_re, const double* w_im, double* g_theta);
+/* per-sample scores S (B,P,2) complex = make_quantum_score(logpsi)  (src/logpsi.py:183-203) */
+int cg_quantum_score(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* score);
+
+/* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
+
+/* RCCL communicator over the ranks of one node; replaces jax.lax.pmean(axis_name="p")
+ * (src/MCMC.py:39, src/VMC.py:46-53,63,72, main.py:280).  unique_id: 128 bytes. */
+int cg_comm_unique_id(void* unique_id_128);
+int cg_comm_create(cg_comm** out, cg_ctx* ctx, int rank, int world, const void* unique_id_128);
+void cg_comm_destroy(cg_comm* comm);
+/* in-place mean over ranks of `count` doubles (DEVICE pointer on the ctx's device) */
+int cg_allreduce_mean(cg_comm* comm, double* buf_dev, size_t count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
