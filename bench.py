@@ -60,7 +60,7 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=12.0)
         noise = rng.standard_normal((steps, Bs, n, dim)); unif = rng.uniform(size=(steps, Bs))
         logp = np.empty(Bs)
         t0 = time.perf_counter()
-        lib.cgo_mcmc(C.c_int(n), C.c_int(dim), C.c_int(16), C.c_int(16), C.c_double(L), p(theta), p(sp), C.c_int(sp.shape[0]),
+        lib.cgo_mcmc(C.c_int(n), C.c_int(dim), C.c_int(2), C.c_int(16), C.c_int(16), C.c_double(L), p(theta), p(sp), C.c_int(sp.shape[0]),
                      p(ss), p(xs), C.c_int(Bs), C.c_int(steps), C.c_double(stddev), p(noise), p(unif), p(logp))
         return time.perf_counter() - t0
     Bs, steps = min(64 * cores, x.shape[0]), 5

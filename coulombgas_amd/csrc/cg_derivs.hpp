@@ -1,13 +1,549 @@
-// placeholder, replaced below
+// cg_derivs.hpp -- derivatives of log Psi for the local energy and the parameter gradient.
+//
+//   grad_laplacian : grad_x log Psi (complex), laplacian_x log Psi (complex)          src/logpsi.py:55-172
+//   param_vjp      : sum_b w_re d/dtheta Re log Psi + w_im d/dtheta Im log Psi         src/VMC.py:69-76 + main.py:278
+//                    and per-sample scores d log Psi / d theta                         src/logpsi.py:183-203
+//
+// The reference nests AD transforms (jvp(jacrev(logpsi)) with jacfwd + slogdet inside logpsi).  Here:
+//   * x-derivatives: one second-order jet (cg_jet.hpp) per direction v through the *same* templated flow +
+//     structured-Jacobian code as the sampler gives z' = J v, z'', J', J''.  With closed forms for the plane-wave
+//     determinant:
+//        d/de   log phi        = sum_ia g_ia z'_ia ,                 g_ia = T^a_ii,  T^a = D diag(i k^a) D^-1
+//        d2/de2 log phi        = g.z'' + sum_i sum_ab z'_ia z'_ib K^ab_ii - tr(Y Y),  Y = sum_a diag(z'_a) T^a,
+//                                                                    K^ab = D diag(-k^a k^b) D^-1
+//        d/de   1/2 log|det J| = 1/2 tr(J^-1 J') ,   d2/de2 = 1/2 [ tr(J^-1 J'') - tr((J^-1 J')^2) ]
+//     exact Laplacian = sum over the n*d basis directions; Hutchinson variants use the supplied probe v.
+//   * theta-gradient: hand-written reverse pass of the structured forward code (adjoint of every phase of
+//     CgFast::primal / CgFast::jacobian), seeded with zbar = w_re Re g + w_im Im g and Jbar = w_re/2 J^-T.
+//
+// One workgroup per walker; intermediates live in a per-workgroup HBM workspace (these kernels run once per
+// optimisation step, not per Metropolis step), LDS is used for the fixed-order reductions only.
 #pragma once
 #include "cg_flow_fast.hpp"
+
 template <int D, int HS, int HT>
 struct CgDerivs {
-    static constexpr bool implemented = false;
-    static size_t ws_doubles(int n) { return 8; }
-    static size_t lds_doubles(int n, int nthr) { return 8; }
-    static CG_DEVI void grad_laplacian(const CgBlk&, const double*, const double*, const double*, const int*, int, double, int,
-                                       const double*, double*, double*, double*, double*) {}
-    static CG_DEVI void param_vjp(const CgBlk&, const double*, const double*, const double*, const int*, int, double, double, double,
-                                  double*, double*, double*, double*) {}
+    using F = CgFast<D, HS, HT>;
+    static constexpr int P = F::P;
+    static constexpr int NP = F::NPARAM;
+
+    struct Ws {   // offsets in doubles into the per-workgroup workspace
+        size_t da, ja, x, xj, Jc, Jinv, M, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, total;
+    };
+    static CG_HD Ws ws_layout(int n) {
+        const size_t N = (size_t)n * D;
+        const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
+        Ws w; size_t t = 0;
+        auto take = [&](size_t c) { size_t r = t; t += (c + 1) & ~(size_t)1; return r; };
+        w.da = take(o.total);             // double arena (primal + jacobian)
+        w.ja = take(3 * (size_t)o.total); // Jet2 arena
+        w.x = take(N); w.xj = take(3 * N);
+        w.Jc = take(N * N); w.Jinv = take(N * N); w.M = take(N * N);
+        w.Dc = take(2 * (size_t)n * n); w.Dinv = take(2 * (size_t)n * n);
+        w.Ta = take(2 * (size_t)D * n * n); w.Kd = take(2 * (size_t)D * D * n);
+        w.gz = take(2 * N); w.zbar = take(N); w.Jbar = take(N * N);
+        w.perm = take(N + 2);
+        w.adj = take(adj_doubles(n));
+        w.gw = take(NP);
+        w.total = t;
+        return w;
+    }
+    static size_t ws_doubles(int n) { return ws_layout(n).total; }
+    static size_t lds_doubles(int n, int nthr) { return (size_t)nthr + 16; }
+
+    // ------------------------------------------------------------------------------------------------------
+    // shared set-up: z, J, J^-1, D, D^-1, g_ia = d log phi / d z_ia.  Returns nothing; everything in ws.
+    // ------------------------------------------------------------------------------------------------------
+    static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
+                              const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                              double* ws, const Ws& w, const CgFastLds& o, bool need_T) {
+        const int N = n * D;
+        double* da = ws + w.da; double* x = ws + w.x;
+        for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
+        b.sync();
+        F::primal(b, th, (const double*)x, n, L, da, o);
+        F::jacobian(b, th, n, L, da, o);
+        double* Jc = ws + w.Jc; double* Jinv = ws + w.Jinv;
+        for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+        b.sync();
+        int* perm = (int*)(ws + w.perm);
+        (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+        double* Dc = ws + w.Dc; double* Dinv = ws + w.Dinv;
+        F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+        for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+        b.sync();
+        double la, ar;
+        cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+        const double* Dm = da + o.Dm;
+        double* Ta = ws + w.Ta; double* Kd = ws + w.Kd; double* gz = ws + w.gz;
+        // g_ia = T^a_ii = sum_j D_ij (i k_j^a) Dinv_ji
+        for (int e = b.tid; e < N; e += b.nthr) {
+            const int i = e / D, a = e - i * D;
+            double re = 0, im = 0;
+            for (int j = 0; j < n; ++j) {
+                const double ka = spk[(size_t)sidx[j] * D + a];
+                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
+                re += -ka * p.im; im += ka * p.re;           // (i k) * p
+            }
+            gz[2 * e] = re; gz[2 * e + 1] = im;
+        }
+        if (need_T) {
+            for (int e = b.tid; e < D * n * n; e += b.nthr) {
+                const int a = e / (n * n), r = e - a * n * n, i = r / n, l = r - i * n;
+                double re = 0, im = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double ka = spk[(size_t)sidx[j] * D + a];
+                    const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + l)], Dinv[2 * (j * n + l) + 1]});
+                    re += -ka * p.im; im += ka * p.re;
+                }
+                Ta[2 * e] = re; Ta[2 * e + 1] = im;
+            }
+            for (int e = b.tid; e < D * D * n; e += b.nthr) {
+                const int a = e / (D * n), r = e - a * D * n, bb = r / n, i = r - bb * n;
+                double re = 0, im = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double kk = -spk[(size_t)sidx[j] * D + a] * spk[(size_t)sidx[j] * D + bb];
+                    const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
+                    re += kk * p.re; im += kk * p.im;
+                }
+                Kd[2 * e] = re; Kd[2 * e + 1] = im;
+            }
+        }
+        b.sync();
+    }
+
+    // one directional jet pass: fills the Jet2 arena (z, J as jets) for direction dir (N doubles, global/ws)
+    static CG_DEVI void jet_pass(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
+                                 const CgFastLds& o, const double* dir, int basis) {
+        const int N = n * D;
+        Jet2* xj = (Jet2*)(ws + w.xj); Jet2* ja = (Jet2*)(ws + w.ja);
+        const double* x = ws + w.x;
+        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
+        b.sync();
+        F::primal(b, th, (const Jet2*)xj, n, L, ja, o);
+        F::jacobian(b, th, n, L, ja, o);
+    }
+
+    static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
+                                       const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                                       int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
+                                       double* __restrict__ lap /*2*/, double* ws, double* lds) {
+        const int N = n * D;
+        const Ws w = ws_layout(n);
+        const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
+        setup(b, th, xg, spk, sidx, n, L, ws, w, o, true);
+        const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
+        const double* gz = ws + w.gz; double* M = ws + w.M;
+        const Jet2* ja = (const Jet2*)(ws + w.ja);
+        double lap_re = 0.0, lap_im = 0.0;
+        const int ndir = N + (mode == 0 ? 0 : 1);
+        for (int dir = 0; dir < ndir; ++dir) {
+            const bool probe = dir == N;
+            jet_pass(b, th, n, L, ws, w, o, probe ? v : nullptr, dir);
+            const Jet2* zj = ja + o.z; const Jet2* Jj = ja + o.J;
+            const bool want_phi2 = probe ? (mode == 1) : (mode == 0 || mode == 2);   // second derivative of log phi
+            const bool want_jac2 = probe ? true : (mode == 0);                        // second derivative of 1/2 log|det J|
+            // ---- Slater part
+            double a_re = 0, a_im = 0, p_re = 0, p_im = 0;
+            for (int e = b.tid; e < N; e += b.nthr) {
+                a_re += gz[2 * e] * zj[e].d; a_im += gz[2 * e + 1] * zj[e].d;
+                if (want_phi2) {
+                    p_re += gz[2 * e] * zj[e].dd; p_im += gz[2 * e + 1] * zj[e].dd;
+                    const int i = e / D, a = e - i * D;
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) {
+                        const double zz = zj[e].d * zj[i * D + bb].d;
+                        p_re += zz * Kd[2 * ((a * D + bb) * n + i)]; p_im += zz * Kd[2 * ((a * D + bb) * n + i) + 1];
+                    }
+                }
+            }
+            if (want_phi2) {
+                for (int e = b.tid; e < n * n; e += b.nthr) {
+                    const int i = e / n, l = e - i * n;
+                    CgCplx yil = {0, 0}, yli = {0, 0};
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double zi = zj[i * D + a].d, zl = zj[l * D + a].d;
+                        yil.re += zi * Ta[2 * ((a * n + i) * n + l)]; yil.im += zi * Ta[2 * ((a * n + i) * n + l) + 1];
+                        yli.re += zl * Ta[2 * ((a * n + l) * n + i)]; yli.im += zl * Ta[2 * ((a * n + l) * n + i) + 1];
+                    }
+                    const CgCplx pr = cmul(yil, yli);
+                    p_re -= pr.re; p_im -= pr.im;
+                }
+            }
+            // ---- Jacobian part: tr(J^-1 J'), tr(J^-1 J''), tr((J^-1 J')^2)
+            double t1 = 0, t2 = 0, t3 = 0;
+            for (int e = b.tid; e < N * N; e += b.nthr) {
+                const int al = e / N, ga = e - al * N;
+                const double ji = Jinv[al * N + ga];
+                t1 += ji * Jj[ga * N + al].d;
+                if (want_jac2) t2 += ji * Jj[ga * N + al].dd;
+            }
+            if (want_jac2) {
+                for (int e = b.tid; e < N * N; e += b.nthr) {
+                    const int al = e / N, ga = e - al * N;
+                    double m = 0;
+                    for (int k = 0; k < N; ++k) m += Jinv[al * N + k] * Jj[k * N + ga].d;
+                    M[e] = m;
+                }
+                b.sync();
+                for (int e = b.tid; e < N * N; e += b.nthr) {
+                    const int al = e / N, ga = e - al * N;
+                    t3 += M[al * N + ga] * M[ga * N + al];
+                }
+            }
+            a_re = cg_block_sum(b, a_re, lds); a_im = cg_block_sum(b, a_im, lds);
+            t1 = cg_block_sum(b, t1, lds);
+            if (want_phi2) { p_re = cg_block_sum(b, p_re, lds); p_im = cg_block_sum(b, p_im, lds); lap_re += p_re; lap_im += p_im; }
+            if (want_jac2) { t2 = cg_block_sum(b, t2, lds); t3 = cg_block_sum(b, t3, lds); lap_re += 0.5 * (t2 - t3); }
+            if (!probe && b.tid == 0) { grad[2 * dir] = a_re + 0.5 * t1; grad[2 * dir + 1] = a_im; }
+            b.sync();
+        }
+        if (b.tid == 0) { lap[0] = lap_re; lap[1] = lap_im; }
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // parameter VJP (reverse pass).  Adjoint scratch layout:
+    // ------------------------------------------------------------------------------------------------------
+    struct Adj { size_t Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, s1b, s2b, u2b, u1b, m1b, gbb, pW0, pWt, su2, total; };
+    static CG_HD Adj adj_layout(int n) {
+        const size_t N = (size_t)n * D;
+        Adj a; size_t t = 0;
+        auto take = [&](size_t c) { size_t r = t; t += (c + 1) & ~(size_t)1; return r; };
+        a.Jhat = take(N * N);
+        a.Upb = take(N * P); a.Vb = take(N * HT); a.Bb = take(N * HS); a.Gb = take((size_t)n * HS * D);
+        a.sg1b = take((size_t)n * HS); a.sg2b = take((size_t)n * HS);
+        a.Ub = take(N * HS); a.Rb = take(N * HS);
+        a.s1b = take((size_t)n * HS); a.s2b = take((size_t)n * HS); a.u2b = take((size_t)n * HS); a.u1b = take((size_t)n * HS);
+        a.m1b = take((size_t)n * HT); a.gbb = take(HS);
+        a.pW0 = take((size_t)n * HS * P);            // per-(p,h) partials of W0bar from the G adjoint
+        a.pWt = take((size_t)n * HT * (P + 1));      // per-(i,h) partials of Wtbar, btbar
+        a.su2 = take(HS);
+        a.total = t;
+        return a;
+    }
+    static CG_HD size_t adj_doubles(int n) { return adj_layout(n).total; }
+
+    // T_pq[f][b] non-zeros for pair features pf of r_pq
+    struct TCol { double tc[D], ts[D], td[D]; };
+    static CG_DEVI void tcols(const typename F::PairF& pf, double c1, double c2c, TCol& t) {
+        const double rdel = 1.0 / pf.del;
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) { t.tc[bb] = -c1 * pf.s2[bb]; t.ts[bb] = c1 * pf.c2[bb]; t.td[bb] = c2c * pf.s2[bb] * rdel; }
+    }
+
+    // One reverse sweep for cotangents (zbar, Jbar); adds the parameter gradient into gw[NP] (gw zeroed by caller).
+    static CG_DEVI void reverse(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
+                                const CgFastLds& o, double* gw) {
+        const int N = n * D;
+        const Adj A = adj_layout(n);
+        double* ad = ws + w.adj;
+        const double* da = ws + w.da;
+        const double *sh = da + o.sh, *ch = da + o.ch, *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
+                     *gbar = da + o.gbar, *sg2 = da + o.sg2, *s2 = da + o.s2, *U = da + o.U, *V = da + o.V,
+                     *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
+        const double* zbar = ws + w.zbar; const double* Jbar = ws + w.Jbar;
+        double *Jhat = ad + A.Jhat, *Upb = ad + A.Upb, *Vb = ad + A.Vb, *Bb = ad + A.Bb, *Gb = ad + A.Gb, *sg1b = ad + A.sg1b,
+               *sg2b = ad + A.sg2b, *Ub = ad + A.Ub, *Rb = ad + A.Rb, *s1b = ad + A.s1b, *s2b = ad + A.s2b, *u2b = ad + A.u2b,
+               *u1b = ad + A.u1b, *m1b = ad + A.m1b, *gbb = ad + A.gbb, *pW0 = ad + A.pW0, *pWt = ad + A.pWt, *su2 = ad + A.su2;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+
+        // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii  (k != i)
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int r = e / N, c = e - r * N, i = r / D, a = r - i * D, k = c / D, bb = c - k * D;
+            Jhat[e] = (i == k) ? 0.0 : Jbar[e] - Jbar[(i * D + a) * N + i * D + bb];
+        }
+        b.sync();
+        // (J5) adjoints that are sums over k for fixed i
+        for (int e = b.tid; e < N * P; e += b.nthr) {              // Upbar_i[a][f] = -sum_k sum_b Jhat_ik[a][b] T_ik[f][b]
+            const int r = e / P, f = e - r * P, i = r / D;
+            double acc = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double tv = (f == bb) ? t.tc[bb] : (f == D + bb) ? t.ts[bb] : (f == 2 * D) ? t.td[bb] : 0.0;
+                    acc -= Jhat[r * N + k * D + bb] * tv;
+                }
+            }
+            Upb[e] = acc;
+        }
+        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]
+            const int r = e / HS, g = e - r * HS;
+            double acc = 0;
+            for (int k = 0; k < n; ++k)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[(k * HS + g) * D + bb];
+            Bb[e] = acc;
+        }
+        for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
+            const int k = e / (HS * D), r = e - k * HS * D, g = r / D, bb = r - g * D;
+            double acc = 0;
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[(i * D + a) * HS + g];
+            Gb[e] = acc;
+        }
+        // (J5) pair pass in (i,h) layout: Vbar_i[:,h], and the sigma_t / q_t adjoints -> partial Wtbar / btbar
+        for (int e = b.tid; e < n * HT; e += b.nthr) {
+            const int i = e / HT, h = e - i * HT;
+            double wt[P]; const double bt = th[F::o_t0b + h];
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
+            double vb[D], pw[P + 1];
+#pragma unroll
+            for (int a = 0; a < D; ++a) vb[a] = 0;
+#pragma unroll
+            for (int f = 0; f <= P; ++f) pw[f] = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+                double u = bt + wt[2 * D] * pf.del, q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
+                }
+                const double sg = sigmoid_only(u), sgp = sg * (1.0 - sg);
+                double sgb = 0, qb[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) qb[bb] = 0;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double vih = V[(i * D + a) * HT + h];
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) {
+                        const double jh = Jhat[(i * D + a) * N + k * D + bb];
+                        vb[a] -= jh * sg * q[bb];
+                        sgb -= jh * vih * q[bb];
+                        qb[bb] -= jh * vih * sg;
+                    }
+                }
+                const double ub = sgb * sgp;          // adjoint of u_t (from sigma_t)
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    pw[a] += qb[a] * t.tc[a] + ub * pf.c2[a];
+                    pw[D + a] += qb[a] * t.ts[a] + ub * pf.s2[a];
+                    pw[2 * D] += qb[a] * t.td[a];
+                }
+                pw[2 * D] += ub * pf.del;
+                pw[P] += ub;
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) Vb[(i * D + a) * HT + h] = vb[a];
+#pragma unroll
+            for (int f = 0; f <= P; ++f) pWt[(size_t)e * (P + 1) + f] = pw[f];
+        }
+        b.sync();
+        // (J4) G adjoint, item (p,h): sg1bar_p[h] (first part) and partial W0bar
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int p = e / HS, h = e - p * HS;
+            double w_c[D], w_s[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
+            const double w_d = th[F::o_W0 + 2 * D * HS + h];
+            const double sgp = sg1[e];
+            double sb = 0, pw[P];
+#pragma unroll
+            for (int f = 0; f < P; ++f) pw[f] = 0;
+            for (int q = 0; q < n; ++q) {
+                if (q == p) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, p, q, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double dG = (Gb[(p * HS + h) * D + bb] - Gb[(q * HS + h) * D + bb]) * rn * rn;
+                    const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
+                    sb += dG * q0;
+                    const double qb = dG * sgp;        // adjoint of q0_pq[h][bb]
+                    pw[bb] += qb * t.tc[bb]; pw[D + bb] += qb * t.ts[bb]; pw[2 * D] += qb * t.td[bb];
+                }
+            }
+            sg1b[e] = sb;
+#pragma unroll
+            for (int f = 0; f < P; ++f) pW0[(size_t)e * P + f] = pw[f];
+        }
+        b.sync();
+        // (J3) Up_i[a][f] = (1/n) sum_g U_i[a][g] sg1_i[g] W0[f][g]
+        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Ubar_i[a][g]
+            const int r = e / HS, g = e - r * HS, i = r / D;
+            double acc = 0;
+#pragma unroll
+            for (int f = 0; f < P; ++f) acc += Upb[r * P + f] * th[F::o_W0 + f * HS + g];
+            Ub[e] = acc * rn * sg1[i * HS + g];
+        }
+        for (int e = b.tid; e < n * HS; e += b.nthr) {             // sg1bar_i[g] += (1/n) sum_{a,f} Upb U W0
+            const int i = e / HS, g = e - i * HS;
+            double acc = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int f = 0; f < P; ++f) acc += Upb[(i * D + a) * P + f] * U[(i * D + a) * HS + g] * th[F::o_W0 + f * HS + g];
+            sg1b[e] += acc * rn;
+        }
+        b.sync();
+        // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]
+        for (int e = b.tid; e < N * HS; e += b.nthr) {
+            const int r = e / HS, h = e - r * HS;
+            double acc = 0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) acc += Ub[r * HS + g] * th[F::o_Wa + g * HS + h] + Bb[r * HS + g] * th[F::o_Wb + g * HS + h];
+#pragma unroll
+            for (int g = 0; g < HT; ++g) acc += rn * Vb[r * HT + g] * th[F::o_Wc + g * HS + h];
+            Rb[e] = acc;
+        }
+        b.sync();
+        // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  (F8) s2bar_i[h] = sum_a Wf[h][a] zbar_i[a]
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double sb = 0, s2 = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) { sb += Rb[(i * D + a) * HS + h] * th[F::o_fw + h * D + a]; s2 += th[F::o_fw + h * D + a] * zbar[i * D + a]; }
+            sg2b[e] = sb; s2b[e] = s2;
+            // (F7) u2bar = s2bar * sg2 + sg2bar * sg2'
+            const double g2 = sg2[e];
+            u2b[e] = s2 * g2 + sb * g2 * (1.0 - g2);
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {                 // sum_i u2bar_i[h]
+            double acc = 0;
+            for (int i = 0; i < n; ++i) acc += u2b[i * HS + h];
+            su2[h] = acc;
+        }
+        b.sync();
+        for (int g = b.tid; g < HS; g += b.nthr) {                 // gbarbar[g] = sum_h Wb[g][h] su2[h]
+            double acc = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wb + g * HS + h] * su2[h];
+            gbb[g] = acc;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * HS; e += b.nthr) {             // s1bar, u1bar
+            const int i = e / HS, g = e - i * HS;
+            double acc = s2b[e] + rn * gbb[g];
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wa + g * HS + h] * u2b[i * HS + h];
+            s1b[e] = acc;
+            const double g1 = sg1[e];
+            u1b[e] = acc * g1 + sg1b[e] * g1 * (1.0 - g1);
+        }
+        for (int e = b.tid; e < n * HT; e += b.nthr) {             // m1bar_i[g] = sum_h Wc[g][h] u2bar_i[h]
+            const int i = e / HT, g = e - i * HT;
+            double acc = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wc + g * HS + h] * u2b[i * HS + h];
+            m1b[e] = acc;
+        }
+        b.sync();
+        // (F4/F5) primal part of the pair stream: utbar_ij[h] = (1/n) m1bar_i[h] sig_t(u_ij[h]);  add to pWt
+        for (int e = b.tid; e < n * HT; e += b.nthr) {
+            const int i = e / HT, h = e - i * HT;
+            double wt[P]; const double bt = th[F::o_t0b + h];
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
+            double pw[P + 1];
+#pragma unroll
+            for (int f = 0; f <= P; ++f) pw[f] = 0;
+            const double mb = m1b[e] * rn;
+            for (int j = 0; j < n; ++j) {
+                typename F::PairF pf; F::pairfeat(sh, ch, i, j, pf);
+                double u = bt + wt[2 * D] * pf.del;
+#pragma unroll
+                for (int a = 0; a < D; ++a) u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                const double ub = mb * sigmoid_only(u);
+#pragma unroll
+                for (int a = 0; a < D; ++a) { pw[a] += ub * pf.c2[a]; pw[D + a] += ub * pf.s2[a]; }
+                pw[2 * D] += ub * pf.del; pw[P] += ub;
+            }
+#pragma unroll
+            for (int f = 0; f <= P; ++f) pWt[(size_t)e * (P + 1) + f] += pw[f];
+        }
+        b.sync();
+        // ---- parameter gradients, one owner thread per parameter (fixed summation order)
+        for (int e = b.tid; e < NP; e += b.nthr) {
+            double acc = 0;
+            if (e < F::o_fw) {                                          // final.b[a]
+                const int a = e - F::o_fb;
+                for (int i = 0; i < n; ++i) acc += zbar[i * D + a];
+            } else if (e < F::o_s0b) {                                  // final.w[h][a]: (F8) + (J1) + direct term of (J2)
+                const int r = e - F::o_fw, h = r / D, a = r - h * D;
+                for (int i = 0; i < n; ++i)
+                    acc += s2[i * HS + h] * zbar[i * D + a] + Rb[(i * D + a) * HS + h] * sg2[i * HS + h] + Ub[(i * D + a) * HS + h];
+            } else if (e < F::o_s0w) {                                  // sp0.b[h]
+                const int h = e - F::o_s0b;
+                for (int i = 0; i < n; ++i) acc += u1b[i * HS + h];
+            } else if (e < F::o_s1b) {                                  // sp0.w[f'][h]; rows < 2D multiply zeros
+                const int r = e - F::o_s0w, fr = r / HS, h = r - fr * HS;
+                if (fr >= 2 * D) {
+                    const int f = fr - 2 * D;
+                    for (int i = 0; i < n; ++i) {
+                        acc += m0[i * P + f] * u1b[i * HS + h] + pW0[((size_t)i * HS + h) * P + f];
+#pragma unroll
+                        for (int a = 0; a < D; ++a) acc += rn * Upb[(i * D + a) * P + f] * U[(i * D + a) * HS + h] * sg1[i * HS + h];
+                    }
+                }
+            } else if (e < F::o_s1w) {                                  // sp1.b[h]
+                acc = su2[e - F::o_s1b];
+            } else if (e < F::o_t0b) {                                  // sp1.w rows: Wa (HS), Wb (HS), Wc (HT)
+                const int r = e - F::o_s1w, g = r / HS, h = r - g * HS;
+                if (g < HS) {
+                    for (int i = 0; i < n; ++i) {
+                        acc += s1[i * HS + g] * u2b[i * HS + h];
+#pragma unroll
+                        for (int a = 0; a < D; ++a) acc += Ub[(i * D + a) * HS + g] * th[F::o_fw + h * D + a] * sg2[i * HS + h];
+                    }
+                } else if (g < 2 * HS) {
+                    const int gg = g - HS;
+                    acc = gbar[gg] * su2[h];
+                    for (int i = 0; i < n; ++i)
+#pragma unroll
+                        for (int a = 0; a < D; ++a) acc += Bb[(i * D + a) * HS + gg] * th[F::o_fw + h * D + a] * sg2[i * HS + h];
+                } else {
+                    const int gg = g - 2 * HS;
+                    for (int i = 0; i < n; ++i) {
+                        acc += m1[i * HT + gg] * u2b[i * HS + h];
+#pragma unroll
+                        for (int a = 0; a < D; ++a) acc += rn * Vb[(i * D + a) * HT + gg] * th[F::o_fw + h * D + a] * sg2[i * HS + h];
+                    }
+                }
+            } else if (e < F::o_t0w) {                                  // tp0.b[h]
+                const int h = e - F::o_t0b;
+                for (int i = 0; i < n; ++i) acc += pWt[((size_t)i * HT + h) * (P + 1) + P];
+            } else {                                                    // tp0.w[f][h]
+                const int r = e - F::o_t0w, f = r / HT, h = r - f * HT;
+                for (int i = 0; i < n; ++i) acc += pWt[((size_t)i * HT + h) * (P + 1) + f];
+            }
+            gw[e] += acc;
+        }
+        b.sync();
+    }
+
+    static CG_DEVI void param_vjp(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
+                                  const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                                  double w_re, double w_im, double* __restrict__ gacc /*NP, nullable*/,
+                                  double* __restrict__ score /*NP x 2, nullable*/, double* ws, double* lds) {
+        const int N = n * D;
+        const Ws w = ws_layout(n);
+        const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
+        setup(b, th, xg, spk, sidx, n, L, ws, w, o, false);
+        const double* Jinv = ws + w.Jinv; const double* gz = ws + w.gz;
+        double* zbar = ws + w.zbar; double* Jbar = ws + w.Jbar; double* gw = ws + w.gw;
+        const int npass = score ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            const double wr = score ? (pass == 0 ? 1.0 : 0.0) : w_re;
+            const double wi = score ? (pass == 0 ? 0.0 : 1.0) : w_im;
+            for (int e = b.tid; e < N; e += b.nthr) zbar[e] = wr * gz[2 * e] + wi * gz[2 * e + 1];
+            for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
+            for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
+            b.sync();
+            reverse(b, th, n, L, ws, w, o, gw);
+            if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
+            else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];
+            b.sync();
+        }
+    }
 };

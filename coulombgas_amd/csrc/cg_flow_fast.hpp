@@ -26,6 +26,7 @@
 #pragma once
 #include "cg_common.hpp"
 #include "cg_linalg.hpp"
+#include "cg_jet.hpp"
 
 // Offsets (in doubles) into the per-walker LDS arena; filled by the host (cg_layout.hpp).
 struct CgFastLds {
@@ -49,37 +50,41 @@ struct CgFast {
     static constexpr int o_Wb = o_s1w + HS * HS;
     static constexpr int o_Wc = o_s1w + 2 * HS * HS;
 
-    struct PairF { double s2[D], c2[D], del; };
+    template <class T> struct PairFT { T s2[D], c2[D], del; };
+    using PairF = PairFT<double>;
 
     // features of r_ij = x_i - x_j from per-particle half-angle tables:
     //   sin(pi r/L) = sh_i ch_j - ch_i sh_j ; cos(2 pi r/L) = 1 - 2 sin^2 ; sin(2 pi r/L) = 2 sin cos
-    static CG_DEVI void pairfeat(const double* sh, const double* ch, int i, int j, PairF& f) {
-        double d2 = 0.0;
+    template <class T>
+    static CG_DEVI void pairfeat(const T* sh, const T* ch, int i, int j, PairFT<T>& f) {
+        T d2 = T(0.0);
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-            const double si = sh[i * D + a], ci = ch[i * D + a], sj = sh[j * D + a], cj = ch[j * D + a];
-            const double s = si * cj - ci * sj, c = ci * cj + si * sj;
-            f.s2[a] = 2.0 * s * c; f.c2[a] = 1.0 - 2.0 * s * s; d2 += s * s;
+            const T si = sh[i * D + a], ci = ch[i * D + a], sj = sh[j * D + a], cj = ch[j * D + a];
+            const T s = si * cj - ci * sj, c = ci * cj + si * sj;
+            f.s2[a] = 2.0 * (s * c); f.c2[a] = 1.0 - 2.0 * (s * s); d2 += s * s;
         }
-        f.del = sqrt(d2);
         if (i == j) {       // exact diagonal feature [1..1, 0..0, 0]  (src/flow.py:25: "* (1 - eye)")
 #pragma unroll
-            for (int a = 0; a < D; ++a) { f.s2[a] = 0.0; f.c2[a] = 1.0; }
-            f.del = 0.0;
+            for (int a = 0; a < D; ++a) { f.s2[a] = T(0.0); f.c2[a] = T(1.0); }
+            f.del = T(0.0);
+        } else {
+            f.del = cg_sqrt(d2);
         }
     }
 
     // ---------------------------------------------------------------------------------------
     // primal pass: fills sh,ch,m0,s1,sg1,m1,gbar,cb,sg2,s2,z in LDS.
     // ---------------------------------------------------------------------------------------
-    static CG_DEVI void primal(const CgBlk& b, const double* __restrict__ th, const double* x /*LDS n*D*/,
-                               int n, double L, double* lds, const CgFastLds& o) {
-        double *sh = lds + o.sh, *ch = lds + o.ch, *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1,
+    template <class T>
+    static CG_DEVI void primal(const CgBlk& b, const double* __restrict__ th, const T* x /*n*D*/,
+                               int n, double L, T* lds, const CgFastLds& o) {
+        T *sh = lds + o.sh, *ch = lds + o.ch, *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1,
                *m1 = lds + o.m1, *gbar = lds + o.gbar, *cb = lds + o.cb, *sg2 = lds + o.sg2, *s2 = lds + o.s2,
                *z = lds + o.z;
         const double rn = 1.0 / (double)n;
         for (int e = b.tid; e < n * D; e += b.nthr) {
-            double s, c; sincos(x[e] * (CG_PI / L), &s, &c);
+            T s, c; cg_sincos(x[e] * (CG_PI / L), s, c);
             sh[e] = s; ch[e] = c;
         }
         b.sync();
@@ -92,16 +97,16 @@ struct CgFast {
 #pragma unroll
             for (int f = 0; f < P; ++f) wt[f] = do_t ? th[o_t0w + f * HT + h] : 0.0;
             if (do_t) bt = th[o_t0b + h];
-            double acc = 0.0, raw = 0.0;
+            T acc = T(0.0), raw = T(0.0);
             for (int j = 0; j < n; ++j) {
-                PairF pf; pairfeat(sh, ch, i, j, pf);
-                double u = bt;
+                PairFT<T> pf; pairfeat(sh, ch, i, j, pf);
+                T u = T(bt);
 #pragma unroll
                 for (int a = 0; a < D; ++a) u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
                 u += wt[2 * D] * pf.del;
-                if (do_t) acc += softplus_only(u);
+                if (do_t) acc += cg_softplus(u);
                 if (h < P) {
-                    double fv = pf.del;
+                    T fv = pf.del;
 #pragma unroll
                     for (int a = 0; a < D; ++a) { if (h == a) fv = pf.c2[a]; if (h == D + a) fv = pf.s2[a]; }
                     raw += fv;
@@ -114,21 +119,21 @@ struct CgFast {
         // layer 0 of the one-particle stream: u1_i = W0^T m0_i + b0 (s0 = 0, src/flow.py:16-18,45)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int i = e / HS, h = e - i * HS;
-            double u = th[o_s0b + h];
+            T u = T(th[o_s0b + h]);
 #pragma unroll
             for (int f = 0; f < P; ++f) u += th[o_W0 + f * HS + h] * m0[i * P + f];
-            double sp, sg; softplus_sigmoid(u, sp, sg);
+            T sp, sg; cg_softplus_sigmoid(u, sp, sg);
             s1[e] = sp; sg1[e] = sg;
         }
         b.sync();
         for (int h = b.tid; h < HS; h += b.nthr) {
-            double a = 0.0;
+            T a = T(0.0);
             for (int i = 0; i < n; ++i) a += s1[i * HS + h];
             gbar[h] = a * rn;
         }
         b.sync();
         for (int h = b.tid; h < HS; h += b.nthr) {
-            double a = th[o_s1b + h];
+            T a = T(th[o_s1b + h]);
 #pragma unroll
             for (int g = 0; g < HS; ++g) a += th[o_Wb + g * HS + h] * gbar[g];
             cb[h] = a;
@@ -137,18 +142,18 @@ struct CgFast {
         // last one-particle layer (residual, src/flow.py:51-52)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int i = e / HS, h = e - i * HS;
-            double u = cb[h];
+            T u = cb[h];
 #pragma unroll
             for (int g = 0; g < HS; ++g) u += th[o_Wa + g * HS + h] * s1[i * HS + g];
 #pragma unroll
             for (int g = 0; g < HT; ++g) u += th[o_Wc + g * HS + h] * m1[i * HT + g];
-            double sp, sg; softplus_sigmoid(u, sp, sg);
+            T sp, sg; cg_softplus_sigmoid(u, sp, sg);
             sg2[e] = sg; s2[e] = s1[e] + sp;
         }
         b.sync();
         for (int e = b.tid; e < n * D; e += b.nthr) {     // z = x + final(s2), src/flow.py:54-55
             const int i = e / D, a = e - i * D;
-            double v = x[e] + th[o_fb + a];
+            T v = x[e] + th[o_fb + a];
 #pragma unroll
             for (int h = 0; h < HS; ++h) v += th[o_fw + h * D + a] * s2[i * HS + h];
             z[e] = v;
@@ -159,20 +164,21 @@ struct CgFast {
     // ---------------------------------------------------------------------------------------
     // Jacobian assembly (needs primal() results in LDS).  Writes J (N x N, N = n*D, row-major).
     // ---------------------------------------------------------------------------------------
+    template <class T>
     static CG_DEVI void jacobian(const CgBlk& b, const double* __restrict__ th, int n, double L,
-                                 double* lds, const CgFastLds& o) {
-        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2;
-        double *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up, *G = lds + o.G, *J = lds + o.J;
+                                 T* lds, const CgFastLds& o) {
+        const T *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2;
+        T *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up, *G = lds + o.G, *J = lds + o.J;
         const int N = n * D;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
         // per-particle left factors: item (i,a,g)
         for (int e = b.tid; e < n * D * HS; e += b.nthr) {
             const int i = e / (D * HS), r = e - i * (D * HS), a = r / HS, g = r - a * HS;
-            double ua = th[o_fw + g * D + a], ub = 0.0;
+            T ua = T(th[o_fw + g * D + a]), ub = T(0.0);
 #pragma unroll
             for (int h = 0; h < HS; ++h) {
-                const double rih = th[o_fw + h * D + a] * sg2[i * HS + h];
+                const T rih = th[o_fw + h * D + a] * sg2[i * HS + h];
                 ua += rih * th[o_Wa + g * HS + h];
                 ub += rih * th[o_Wb + g * HS + h];
             }
@@ -180,9 +186,9 @@ struct CgFast {
         }
         for (int e = b.tid; e < n * D * HT; e += b.nthr) {
             const int i = e / (D * HT), r = e - i * (D * HT), a = r / HT, g = r - a * HT;
-            double v = 0.0;
+            T v = T(0.0);
 #pragma unroll
-            for (int h = 0; h < HS; ++h) v += th[o_fw + h * D + a] * sg2[i * HS + h] * th[o_Wc + g * HS + h];
+            for (int h = 0; h < HS; ++h) v += (th[o_fw + h * D + a] * th[o_Wc + g * HS + h]) * sg2[i * HS + h];
             V[e] = v * rn;
         }
         // G pass: item (k,h)
@@ -192,19 +198,19 @@ struct CgFast {
 #pragma unroll
             for (int a = 0; a < D; ++a) { w_c[a] = th[o_W0 + a * HS + h]; w_s[a] = th[o_W0 + (D + a) * HS + h]; }
             const double w_d = th[o_W0 + 2 * D * HS + h];
-            const double sgk = sg1[k * HS + h];
-            double acc[D];
+            const T sgk = sg1[k * HS + h];
+            T acc[D];
 #pragma unroll
-            for (int a = 0; a < D; ++a) acc[a] = 0.0;
+            for (int a = 0; a < D; ++a) acc[a] = T(0.0);
             for (int l = 0; l < n; ++l) {
                 if (l == k) continue;
-                PairF pf; pairfeat(sh, ch, k, l, pf);
-                const double rdel = 1.0 / pf.del;
-                const double sgl = sg1[l * HS + h];
+                PairFT<T> pf; pairfeat(sh, ch, k, l, pf);
+                const T rdel = cg_rcp(pf.del);
+                const T sgl = sg1[l * HS + h];
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) {
-                    const double odd = -c1 * pf.s2[bb] * w_c[bb] + c2c * pf.s2[bb] * rdel * w_d;   // odd in r
-                    const double evn = c1 * pf.c2[bb] * w_s[bb];                                  // even in r
+                    const T odd = (-c1 * w_c[bb]) * pf.s2[bb] + (c2c * w_d) * (pf.s2[bb] * rdel);   // odd in r
+                    const T evn = (c1 * w_s[bb]) * pf.c2[bb];                                       // even in r
                     // (W0^T T_kl)[h,bb] = odd + evn ;  (W0^T T_lk)[h,bb] = -odd + evn
                     acc[bb] += sgk * (odd + evn) - sgl * (evn - odd);
                 }
@@ -215,9 +221,9 @@ struct CgFast {
         b.sync();
         for (int e = b.tid; e < n * D * P; e += b.nthr) {      // U'_i: item (i,a,f)
             const int i = e / (D * P), r = e - i * (D * P), a = r / P, f = r - a * P;
-            double v = 0.0;
+            T v = T(0.0);
 #pragma unroll
-            for (int g = 0; g < HS; ++g) v += U[(i * D + a) * HS + g] * sg1[i * HS + g] * th[o_W0 + f * HS + g];
+            for (int g = 0; g < HS; ++g) v += th[o_W0 + f * HS + g] * (U[(i * D + a) * HS + g] * sg1[i * HS + g]);
             Up[e] = v * rn;
         }
         b.sync();
@@ -225,12 +231,12 @@ struct CgFast {
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, k = e - i * n;
             if (i == k) continue;
-            PairF pf; pairfeat(sh, ch, i, k, pf);
-            const double rdel = 1.0 / pf.del;
-            double tc[D], ts[D], td[D];
+            PairFT<T> pf; pairfeat(sh, ch, i, k, pf);
+            const T rdel = cg_rcp(pf.del);
+            T tc[D], ts[D], td[D];
 #pragma unroll
-            for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * pf.s2[bb] * rdel; }
-            double Jb[D][D];
+            for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * (pf.s2[bb] * rdel); }
+            T Jb[D][D];
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -239,18 +245,18 @@ struct CgFast {
                                   Up[(i * D + a) * P + 2 * D] * td[bb]);
 #pragma unroll 4
             for (int h = 0; h < HT; ++h) {
-                double u = th[o_t0b + h] + th[o_t0w + 2 * D * HT + h] * pf.del;
-                double q[D];
+                T u = th[o_t0b + h] + th[o_t0w + 2 * D * HT + h] * pf.del;
+                T q[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
                     const double wc = th[o_t0w + a * HT + h], ws = th[o_t0w + (D + a) * HT + h];
                     u += wc * pf.c2[a] + ws * pf.s2[a];
                     q[a] = wc * tc[a] + ws * ts[a] + th[o_t0w + 2 * D * HT + h] * td[a];
                 }
-                const double sg = sigmoid_only(u);
+                const T sg = cg_sigmoid(u);
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const double vs = V[(i * D + a) * HT + h] * sg;
+                    const T vs = V[(i * D + a) * HT + h] * sg;
 #pragma unroll
                     for (int bb = 0; bb < D; ++bb) Jb[a][bb] -= vs * q[bb];
                 }
@@ -259,7 +265,7 @@ struct CgFast {
             for (int g = 0; g < HS; ++g) {
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const double bg = Bm[(i * D + a) * HS + g];
+                    const T bg = Bm[(i * D + a) * HS + g];
 #pragma unroll
                     for (int bb = 0; bb < D; ++bb) Jb[a][bb] += bg * G[(k * HS + g) * D + bb];
                 }
@@ -273,7 +279,7 @@ struct CgFast {
         // diagonal blocks from sum_k J_ik = I
         for (int e = b.tid; e < n * D * D; e += b.nthr) {
             const int i = e / (D * D), r = e - i * (D * D), a = r / D, bb = r - a * D;
-            double v = (a == bb) ? 1.0 : 0.0;
+            T v = T((a == bb) ? 1.0 : 0.0);
             for (int k = 0; k < n; ++k)
                 if (k != i) v -= J[(i * D + a) * N + k * D + bb];
             J[(i * D + a) * N + i * D + bb] = v;

@@ -37,3 +37,45 @@ extern "C" int emu_logpsi(int n, int dim, int hs, int ht, double L, const double
 #undef CG_X
     return -1;
 }
+
+// ---- derivative kernels (cg_derivs.hpp) on the host shim ----
+#include "../../coulombgas_amd/csrc/cg_derivs.hpp"
+
+template <int D, int HS, int HT>
+static void emu_gradlap_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+                          const double* x, int B, int mode, const double* v, double* grad, double* lap) {
+    using G = CgDerivs<D, HS, HT>;
+    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + 8), spk((size_t)M * D);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    for (int w = 0; w < B; ++w)
+        G::grad_laplacian(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
+                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data());
+}
+extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                                  const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap) {
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_gradlap_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, mode, v, grad, lap); return 0; }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    return -1;
+}
+
+template <int D, int HS, int HT>
+static void emu_vjp_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+                      const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
+    using G = CgDerivs<D, HS, HT>;
+    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + 8), spk((size_t)M * D);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    if (g) for (int e = 0; e < G::NP; ++e) g[e] = 0.0;
+    for (int w = 0; w < B; ++w)
+        G::param_vjp(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, w_re ? w_re[w] : 1.0,
+                     w_im ? w_im[w] : 0.0, g, score ? score + (size_t)w * G::NP * 2 : nullptr, ws.data(), lds.data());
+}
+extern "C" int emu_param_vjp(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                             const int* sidx, const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_vjp_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, w_re, w_im, g, score); return 0; }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    return -1;
+}
