@@ -27,10 +27,28 @@ struct CgDerivs {
     static constexpr int P = F::P;
     static constexpr int NP = F::NPARAM;
 
+    struct Adj { size_t Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, s1b, s2b, u2b, u1b, m1b, gbb, pW0, pWt, su2, total; };
+    static Adj adj_layout(int n) {
+        const size_t N = (size_t)n * D;
+        Adj a; size_t t = 0;
+        auto take = [&](size_t c) { size_t r = t; t += (c + 1) & ~(size_t)1; return r; };
+        a.Jhat = take(N * N);
+        a.Upb = take(N * P); a.Vb = take(N * HT); a.Bb = take(N * HS); a.Gb = take((size_t)n * HS * D);
+        a.sg1b = take((size_t)n * HS); a.sg2b = take((size_t)n * HS);
+        a.Ub = take(N * HS); a.Rb = take(N * HS);
+        a.s1b = take((size_t)n * HS); a.s2b = take((size_t)n * HS); a.u2b = take((size_t)n * HS); a.u1b = take((size_t)n * HS);
+        a.m1b = take((size_t)n * HT); a.gbb = take(HS);
+        a.pW0 = take((size_t)n * HS * P);            // per-(p,h) partials of W0bar from the G adjoint
+        a.pWt = take((size_t)n * HT * (P + 1));      // per-(i,h) partials of Wtbar, btbar
+        a.su2 = take(HS);
+        a.total = t;
+        return a;
+    }
+    static size_t adj_doubles(int n) { return adj_layout(n).total; }
     struct Ws {   // offsets in doubles into the per-workgroup workspace
         size_t da, ja, x, xj, Jc, Jinv, M, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, total;
     };
-    static CG_HD Ws ws_layout(int n) {
+    static Ws ws_layout(int n) {
         const size_t N = (size_t)n * D;
         const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
         Ws w; size_t t = 0;
@@ -48,6 +66,8 @@ struct CgDerivs {
         w.total = t;
         return w;
     }
+    struct Layout { Ws w; Adj a; CgFastLds o; };
+    static Layout layout(int n) { Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false); return l; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static size_t lds_doubles(int n, int nthr) { return (size_t)nthr + 16; }
 
@@ -127,10 +147,10 @@ struct CgDerivs {
     static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                                        const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                                        int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
-                                       double* __restrict__ lap /*2*/, double* ws, double* lds) {
+                                       double* __restrict__ lap /*2*/, double* ws, double* lds, const Layout& lay) {
         const int N = n * D;
-        const Ws w = ws_layout(n);
-        const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
+        const Ws& w = lay.w;
+        const CgFastLds& o = lay.o;
         setup(b, th, xg, spk, sidx, n, L, ws, w, o, true);
         const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
         const double* gz = ws + w.gz; double* M = ws + w.M;
@@ -205,25 +225,6 @@ struct CgDerivs {
     // ------------------------------------------------------------------------------------------------------
     // parameter VJP (reverse pass).  Adjoint scratch layout:
     // ------------------------------------------------------------------------------------------------------
-    struct Adj { size_t Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, s1b, s2b, u2b, u1b, m1b, gbb, pW0, pWt, su2, total; };
-    static CG_HD Adj adj_layout(int n) {
-        const size_t N = (size_t)n * D;
-        Adj a; size_t t = 0;
-        auto take = [&](size_t c) { size_t r = t; t += (c + 1) & ~(size_t)1; return r; };
-        a.Jhat = take(N * N);
-        a.Upb = take(N * P); a.Vb = take(N * HT); a.Bb = take(N * HS); a.Gb = take((size_t)n * HS * D);
-        a.sg1b = take((size_t)n * HS); a.sg2b = take((size_t)n * HS);
-        a.Ub = take(N * HS); a.Rb = take(N * HS);
-        a.s1b = take((size_t)n * HS); a.s2b = take((size_t)n * HS); a.u2b = take((size_t)n * HS); a.u1b = take((size_t)n * HS);
-        a.m1b = take((size_t)n * HT); a.gbb = take(HS);
-        a.pW0 = take((size_t)n * HS * P);            // per-(p,h) partials of W0bar from the G adjoint
-        a.pWt = take((size_t)n * HT * (P + 1));      // per-(i,h) partials of Wtbar, btbar
-        a.su2 = take(HS);
-        a.total = t;
-        return a;
-    }
-    static CG_HD size_t adj_doubles(int n) { return adj_layout(n).total; }
-
     // T_pq[f][b] non-zeros for pair features pf of r_pq
     struct TCol { double tc[D], ts[D], td[D]; };
     static CG_DEVI void tcols(const typename F::PairF& pf, double c1, double c2c, TCol& t) {
@@ -234,9 +235,8 @@ struct CgDerivs {
 
     // One reverse sweep for cotangents (zbar, Jbar); adds the parameter gradient into gw[NP] (gw zeroed by caller).
     static CG_DEVI void reverse(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                const CgFastLds& o, double* gw) {
+                                const CgFastLds& o, const Adj& A, double* gw) {
         const int N = n * D;
-        const Adj A = adj_layout(n);
         double* ad = ws + w.adj;
         const double* da = ws + w.da;
         const double *sh = da + o.sh, *ch = da + o.ch, *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
@@ -525,10 +525,10 @@ struct CgDerivs {
     static CG_DEVI void param_vjp(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                                   const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                                   double w_re, double w_im, double* __restrict__ gacc /*NP, nullable*/,
-                                  double* __restrict__ score /*NP x 2, nullable*/, double* ws, double* lds) {
+                                  double* __restrict__ score /*NP x 2, nullable*/, double* ws, double* lds, const Layout& lay) {
         const int N = n * D;
-        const Ws w = ws_layout(n);
-        const CgFastLds o = cg_fast_layout(n, D, HS, HT, false);
+        const Ws& w = lay.w;
+        const CgFastLds& o = lay.o;
         setup(b, th, xg, spk, sidx, n, L, ws, w, o, false);
         const double* Jinv = ws + w.Jinv; const double* gz = ws + w.gz;
         double* zbar = ws + w.zbar; double* Jbar = ws + w.Jbar; double* gw = ws + w.gw;
@@ -540,7 +540,7 @@ struct CgDerivs {
             for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
             for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
             b.sync();
-            reverse(b, th, n, L, ws, w, o, gw);
+            reverse(b, th, n, L, ws, w, o, lay.a, gw);
             if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
             else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];
             b.sync();

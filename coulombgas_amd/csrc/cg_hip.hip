@@ -145,14 +145,14 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 template <int D, int HS, int HT>
 __global__ void k_grad_lap(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
-                           double* __restrict__ ws, size_t ws_per_walker) {
+                           double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     extern __shared__ double lds[];
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     const int n = m.n, N = n * D;
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
         CgDerivs<D, HS, HT>::grad_laplacian(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L, mode,
                                             v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
-                                            ws + (size_t)blockIdx.x * ws_per_walker, lds);
+                                            ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
         b.sync();
     }
 }
@@ -161,7 +161,7 @@ template <int D, int HS, int HT>
 __global__ void k_param_vjp(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
-                            double* __restrict__ ws, size_t ws_per_walker) {
+                            double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     extern __shared__ double lds[];
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     const int n = m.n, N = n * D;
@@ -173,7 +173,7 @@ __global__ void k_param_vjp(CgDev m, const double* __restrict__ x, const int* __
         CgDerivs<D, HS, HT>::param_vjp(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L,
                                        w_re ? w_re[w] : 1.0, w_im ? w_im[w] : 0.0, gacc,
                                        score ? score + (size_t)w * P * 2 : nullptr,
-                                       ws + (size_t)blockIdx.x * ws_per_walker, lds);
+                                       ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
         b.sync();
     }
 }
@@ -723,7 +723,7 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
         if ((rc = set_lds(c, k_grad_lap<D, HS, HT>, lds))) return rc;                                               \
         hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
                            (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev,    \
-                           (double*)c->ws, wsw);                                                                    \
+                           (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                                    \
         launched = true;                                                                                            \
     }
     CG_FAST_CONFIGS(CG_X)
@@ -766,7 +766,7 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
         if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
         hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
                            (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
-                           (double*)asc.dev, (double*)c->ws, wsw);                                                   \
+                           (double*)asc.dev, (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                   \
         launched = true;                                                                                             \
     }
     CG_FAST_CONFIGS(CG_X)

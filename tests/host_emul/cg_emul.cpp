@@ -5,6 +5,8 @@
 // coulombgas_amd package: the product path is the HIP library only.
 #include <vector>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include "../../coulombgas_amd/csrc/cg_common.hpp"
 #include "../../coulombgas_amd/csrc/cg_linalg.hpp"
 #include "../../coulombgas_amd/csrc/cg_flow_fast.hpp"
@@ -50,7 +52,7 @@ static void emu_gradlap_t(int n, double L, const double* theta, const double* sp
     CgBlk b{0, 1};
     for (int w = 0; w < B; ++w)
         G::grad_laplacian(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
-                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data());
+                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data(), G::layout(n));
 }
 extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
                                   const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap) {
@@ -70,7 +72,7 @@ static void emu_vjp_t(int n, double L, const double* theta, const double* sp_ind
     if (g) for (int e = 0; e < G::NP; ++e) g[e] = 0.0;
     for (int w = 0; w < B; ++w)
         G::param_vjp(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, w_re ? w_re[w] : 1.0,
-                     w_im ? w_im[w] : 0.0, g, score ? score + (size_t)w * G::NP * 2 : nullptr, ws.data(), lds.data());
+                     w_im ? w_im[w] : 0.0, g, score ? score + (size_t)w * G::NP * 2 : nullptr, ws.data(), lds.data(), G::layout(n));
 }
 extern "C" int emu_param_vjp(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
                              const int* sidx, const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
@@ -78,4 +80,58 @@ extern "C" int emu_param_vjp(int n, int dim, int hs, int ht, double L, const dou
     CG_FAST_CONFIGS(CG_X)
 #undef CG_X
     return -1;
+}
+
+// ---- sampler and Ewald on the host shim (supplied noise only) ----
+#include "../../coulombgas_amd/csrc/cg_ewald.hpp"
+
+template <int D, int HS, int HT>
+static long emu_mcmc_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx, double* x, int B,
+                       int steps, double stddev, const double* noise, const double* unif, double* logp_out) {
+    using F = CgFast<D, HS, HT>;
+    const int N = n * D;
+    CgFastLds o = cg_fast_layout(n, D, HS, HT, true);       // the aliased layout the GPU kernel uses
+    std::vector<double> lds(o.total + 8), xc(N), xp(N), spk((size_t)M * D);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    long total = 0;
+    for (int w = 0; w < B; ++w) {
+        memcpy(xc.data(), x + (size_t)w * N, sizeof(double) * N);
+        double re, im, h;
+        F::logpsi(b, theta, xc.data(), spk.data(), sidx + (size_t)w * n, n, L, lds.data(), o, re, im, h);
+        double logp = 2.0 * (re + h);
+        for (int s = 0; s < steps; ++s) {
+            for (int e = 0; e < N; ++e) xp[e] = xc[e] + stddev * noise[((size_t)s * B + w) * N + e];
+            F::logpsi(b, theta, xp.data(), spk.data(), sidx + (size_t)w * n, n, L, lds.data(), o, re, im, h);
+            const double lp = 2.0 * (re + h);
+            if (unif[(size_t)s * B + w] < exp(lp - logp)) { xc = xp; logp = lp; ++total; }
+        }
+        memcpy(x + (size_t)w * N, xc.data(), sizeof(double) * N);
+        if (logp_out) logp_out[w] = logp;
+    }
+    return total;
+}
+extern "C" long emu_mcmc(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+                         double* x, int B, int steps, double stddev, const double* noise, const double* unif, double* logp_out) {
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) return emu_mcmc_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, steps, stddev, noise, unif, logp_out);
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    return -1;
+}
+
+extern "C" int emu_ewald(int n, int dim, double L, double kappa, double rs, const long* G, int nG, const double* x, int B, double* V) {
+    std::vector<int> g32((size_t)nG * dim); std::vector<double> gk(nG);
+    int gmax = 0;
+    for (int g = 0; g < nG; ++g) {
+        double g2 = 0;
+        for (int a = 0; a < dim; ++a) { g32[g * dim + a] = (int)G[g * dim + a]; gmax = std::max(gmax, std::abs((int)G[g * dim + a])); g2 += (double)G[g * dim + a] * G[g * dim + a]; }
+        gk[g] = dim == 3 ? exp(-CG_PI * CG_PI * g2 / (kappa * kappa)) / (CG_PI * g2) : erfc(CG_PI * sqrt(g2) / kappa) / sqrt(g2);
+    }
+    const double g0 = dim == 3 ? -CG_PI / (kappa * kappa) : -2.0 * sqrt(CG_PI) / kappa;
+    std::vector<double> lds((size_t)n * dim * (gmax + 1) * 2 + 16);
+    CgBlk b{0, 1};
+    for (int w = 0; w < B; ++w)
+        V[w] = dim == 2 ? cg_ewald_walker<2>(b, x + (size_t)w * n * dim, n, L, kappa, rs, g32.data(), gk.data(), nG, gmax, g0, lds.data())
+                        : cg_ewald_walker<3>(b, x + (size_t)w * n * dim, n, L, kappa, rs, g32.data(), gk.data(), nG, gmax, g0, lds.data());
+    return 0;
 }

@@ -149,3 +149,133 @@ def test_wrap_and_errors():
     # empty batch
     eng.set_params(s["theta"])
     assert eng.logp(np.zeros((0, 13, 2)), np.zeros((0, 13), dtype=np.int32)).shape == (0,)
+
+
+# ---------------------------------------------------------------------------------------------
+# derivatives: grad / Laplacian (src/logpsi.py:55-172), theta-VJP and scores, make_loss
+# ---------------------------------------------------------------------------------------------
+DCASES = [(5, 2, 4, 4, 2.0, 0.4, 0.2), (7, 3, 4, 4, 1.234, 0.4, 0.2), (13, 2, 16, 16, None, 0.2, 0.1)]
+
+
+@pytest.mark.parametrize("case", DCASES)
+def test_grad_laplacian_all_modes(case):
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    B = 2
+    s = _setup(case, B, seed=11)
+    v = s["rng"].standard_normal(s["x"].shape)
+    logpsi = cg.make_logpsi(s["flow"], s["sp"], s["L"])
+    logphi, logjacdet = cg.make_logphi_logjacdet(s["flow"], s["sp"], s["L"])
+    r_logpsi = R.make_logpsi(s["rflow"], s["sp"], s["L"])
+    r_logphi, r_logjacdet = R.make_logphi_logjacdet(s["rflow"], s["sp"], s["L"])
+    sb = torch.as_tensor(s["sidx"].astype(np.int64))
+    variants = [(dict(), dict()),
+                (dict(hutchinson=True), dict(hutchinson=True)),
+                (dict(hutchinson=True, logphi=logphi, logjacdet=logjacdet), dict(hutchinson=True, logphi=r_logphi, logjacdet=r_logjacdet))]
+    grads = []
+    for kw, rkw in variants:
+        _, fn = cg.make_logpsi_grad_laplacian(logpsi, **kw)
+        _, rfn = R.make_logpsi_grad_laplacian(r_logpsi, **rkw)
+        g, l = fn(s["x"], s["theta"], s["sidx"], v)                # key = explicit probe array
+        gr, lr = rfn(R.T(s["x"]), s["rparams"], sb, R.T(v))
+        gr, lr = gr.numpy(), lr.numpy()
+        assert g.shape == s["x"].shape and l.shape == (B,)
+        assert np.abs(g - gr).max() < 1e-10 * max(1.0, np.abs(gr).max())
+        assert np.abs(l - lr).max() < 1e-9 * max(1.0, np.abs(lr).max())
+        grads.append(g)
+    # tests/test_logpsi.py:151: the Hutchinson variants return the exact gradient
+    assert np.abs(grads[1] - grads[0]).max() < 1e-10 * max(1.0, np.abs(grads[0]).max())
+    assert np.abs(grads[2] - grads[0]).max() < 1e-10 * max(1.0, np.abs(grads[0]).max())
+
+
+@pytest.mark.parametrize("n,dim,L", [(7, 3, 1.234), (13, 2, None)])
+def test_kinetic_energy_identity_flow(n, dim, L):
+    """Analytic KAT of the reference (tests/test_logpsi.py:79-106, tests/test_slater.py:81-112): with an identity flow
+    (all flow parameters zero) -lap - sum grad^2 = (2 pi / L)^2 sum |n|^2, through the full GPU path."""
+    import coulombgas_amd as cg
+    L = box_length(n, dim) if L is None else L
+    rng = np.random.default_rng(2)
+    sp = orbitals(dim)
+    flow = cg.FermiNet(2, 16, 16, L)
+    theta = np.zeros(flow.engine(n, dim, sp).P)
+    x = walkers(rng, 3, n, dim, L)
+    sidx = state_indices(rng, 3, n, sp.shape[0])
+    logpsi = cg.make_logpsi(flow, sp, L)
+    for kw in (dict(), dict(hutchinson=True, logphi=1, logjacdet=1)):
+        _, fn = cg.make_logpsi_grad_laplacian(logpsi, **kw)
+        g, l = fn(x, theta, sidx, 7)
+        kin = -l - (g ** 2).sum(axis=(-2, -1))
+        ref = (2 * np.pi / L) ** 2 * (sp[sidx] ** 2).sum(axis=(-2, -1))
+        assert np.abs(kin - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("case", DCASES)
+def test_param_vjp_and_scores(case):
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    n, dim, hs, ht = case[:4]
+    B = 3
+    s = _setup(case, B, seed=13)
+    rng = s["rng"]
+    w_re, w_im = rng.standard_normal(B), rng.standard_normal(B)
+    eng = s["flow"].engine(n, dim, s["sp"])
+    eng.set_params(s["theta"])
+    g = eng.param_vjp(s["x"], s["sidx"], w_re, w_im)
+    r_logpsi = R.make_logpsi(s["rflow"], s["sp"], s["L"])
+    sb = torch.as_tensor(s["sidx"].astype(np.int64))
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, 2, hs, ht, dim), sbb)
+
+    def S(th):
+        out = torch.stack([lpt(R.T(s["x"][b]), th, sb[b]) for b in range(B)])
+        return (R.T(w_re) * out[:, 0] + R.T(w_im) * out[:, 1]).sum()
+    gr = torch.func.grad(S)(R.T(s["theta"])).numpy()
+    assert np.abs(g - gr).max() < 1e-10 * max(1.0, np.abs(gr).max())
+    qs = cg.make_quantum_score(cg.make_logpsi(s["flow"], s["sp"], s["L"]))(s["x"], s["theta"], s["sidx"])
+    qr = R.make_quantum_score(lpt)(R.T(s["x"]), R.T(s["theta"]), sb).numpy()
+    flat = np.concatenate([qs[nm][lf].reshape(B, -1) for nm, lf, _ in cg.flow.ravel_order(2, hs, ht, dim)], axis=1)
+    assert np.abs(flat - qr).max() < 1e-10 * max(1.0, np.abs(qr).max())
+
+
+def test_make_loss_against_oracle():
+    """src/VMC.py:31-80 + main.py:277-278 on one device: observables, complex clip, loss values and theta-gradients."""
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    case = (13, 2, 16, 16, None, 0.1, 0.05)
+    n, dim, hs, ht = case[:4]
+    B = 6
+    s = _setup(case, B, seed=17)
+    rng = s["rng"]
+    L, rs, kappa, beta = s["L"], 10.0, 10, 1 / (4 * 0.15)
+    G = cg.kpoints(dim, 15)
+    Vconst = n * rs / L * cg.Madelung(dim, kappa, G)
+    logp_states = -5.0 + rng.standard_normal(B)
+    log_prob = lambda params_van, state_indices: logp_states
+    v = rng.standard_normal(s["x"].shape)
+    logpsi_novmap = cg.make_logpsi(s["flow"], s["sp"], L)
+    logphi, logjacdet = cg.make_logphi_logjacdet(s["flow"], s["sp"], L)
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi_novmap, hutchinson=True, logphi=logphi, logjacdet=logjacdet)
+    obs_fn = cg.make_loss(log_prob, logpsi, lgl, kappa, G, L, rs, Vconst, beta)
+    obs, closs, qloss = obs_fn(None, s["theta"], s["sidx"], s["x"], v)
+    qv = qloss(s["theta"])
+    cv = closs(None)
+    g_grad, g_score = qloss.grad(s["theta"], as_pytree=False)
+    # oracle
+    r_logpsi = R.make_logpsi(s["rflow"], s["sp"], L)
+    r_logphi, r_logjacdet = R.make_logphi_logjacdet(s["rflow"], s["sp"], L)
+    _, rfn = R.make_logpsi_grad_laplacian(r_logpsi, hutchinson=True, logphi=r_logphi, logjacdet=r_logjacdet)
+    sb = torch.as_tensor(s["sidx"].astype(np.int64))
+    gr, lr = rfn(R.T(s["x"]), s["rparams"], sb, R.T(v))
+    pot = R.potential_energy(R.T(s["x"]), kappa, G, L, rs)
+    robs, Eloc, Floc, Fc, Ec = R.observables_and_weights(R.T(logp_states), gr, lr, pot, Vconst, beta)
+    for k in robs:
+        assert obs[k] == pytest.approx(float(robs[k]), rel=1e-9, abs=1e-9), k
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, 2, hs, ht, dim), sbb)
+    v0, v1, dg, ds = R.quantum_loss_and_grads(lpt, R.T(s["theta"]), R.T(s["x"]), sb, Ec)
+    assert qv[0] == pytest.approx(float(v0), rel=1e-9, abs=1e-9) and qv[1] == pytest.approx(float(v1), rel=1e-10)
+    assert np.abs(g_grad - dg.numpy()).max() < 1e-9 * max(1.0, np.abs(dg.numpy()).max())
+    assert np.abs(g_score - ds.numpy()).max() < 1e-10 * max(1.0, np.abs(ds.numpy()).max())
+    assert cv[0] == pytest.approx(float((R.T(logp_states) * Fc).mean()), rel=1e-10)
+    assert cv[1] == pytest.approx(float(logp_states.mean()), rel=1e-12)
+    # main.py:295-298 final-step combination stays host algebra: grad - <E> score
+    final = g_grad - obs["E_mean"] * g_score
+    assert np.isfinite(final).all()
