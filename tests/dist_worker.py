@@ -1,0 +1,48 @@
+"""Worker for tests/test_distributed_gloo.py: one rank of a world_size-N gloo job (CPU).  Each rank owns a shard of
+the walker batch (main.py:231-236), runs the host logic with the emulated engine and the TorchDistComm, and writes
+what it computed; rank 0's parent compares with the single-process result on the full batch."""
+import json, os, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir = sys.argv[1]
+    import torch.distributed as dist
+    dist.init_process_group("gloo")           # MASTER_ADDR=127.0.0.1 from the launcher
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import coulombgas_amd as cg
+    import coulombgas_amd.flow as fl
+    from coulombgas_amd.comm import TorchDistComm, set_comm
+    from tests import emul_engine
+    from tests.test_host_logic import _problem, build_loss
+
+    class MP:       # minimal monkeypatch stand-in
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    emul_engine.install(MP())
+    comm = TorchDistComm()
+    set_comm(comm)
+    pb = _problem(B=8)
+    B = pb["x"].shape[0] // world
+    sl = slice(rank * B, (rank + 1) * B)                                   # this rank's walkers
+    obs_fn, G, Vconst = build_loss(pb)                                     # uses get_comm()
+    obs, closs, qloss = obs_fn(pb["logp_states"][sl], pb["theta"], pb["sidx"][sl], pb["x"][sl], pb["v"][sl])
+    qv = comm.pmean(np.array(qloss(pb["theta"])))                      # per-device means, pmean'd like main.py:280
+    g, s = qloss.grad(pb["theta"], as_pytree=False)
+    g, s = comm.pmean(g), comm.pmean(s)                                    # main.py:280
+    # sampling call: distinct streams per rank, pmean'd accept rate (src/MCMC.py:39)
+    flow = cg.FermiNet(2, 16, 16, pb["L"])
+    logp = cg.make_logp(cg.make_logpsi(flow, pb["sp"], pb["L"]))
+    key = np.random.SeedSequence(7).spawn(world)[rank]                      # jax.random.split(key, num_devices), main.py:237
+    _, sidx, x, rate = cg.sample_stateindices_and_x(key, lambda pv, k, b: pb["sidx"][sl], None, logp, pb["x"][sl], pb["theta"], 4, 0.1, pb["L"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=np.array([obs[k] for k in sorted(obs)]), qv=np.array(qv), g=g, s=s,
+             rate=rate, x=x, tvE=float(np.abs(obs_fn.Eloc - obs["E_mean"]).mean()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+"""N > 1 path on CPU: world_size-2 gloo job (one process per 'device') vs the single-process result on the full
+batch.  Covers the pmean sites of src/MCMC.py:39, src/VMC.py:46-53,63,72 and main.py:280 as implemented by
+coulombgas_amd.comm, and the per-rank sharding of walkers (main.py:231-237)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_match_single_process(tmp_path, monkeypatch):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=580)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # every rank holds the same reduced values
+    for k in ("obs", "qv", "g", "s", "rate"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert not np.array_equal(r0["x"], r1["x"])                 # different walkers per rank
+    # single process, full batch
+    from tests import emul_engine
+    from tests.test_host_logic import _problem, build_loss
+    emul_engine.install(monkeypatch)
+    pb = _problem(B=8)
+    obs_fn, G, Vconst = build_loss(pb)
+    obs, closs, qloss = obs_fn(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"])
+    full = np.array([obs[k] for k in sorted(obs)])
+    assert np.abs(r0["obs"] - full).max() < 1e-11 * np.abs(full).max()      # mean of shard means == batch mean
+    qv = np.array(qloss(pb["theta"]))
+    assert np.abs(r0["qv"] - qv).max() < 1e-10 * max(1.0, np.abs(qv).max())  # same clip width (pmean'd tv) on both paths
+    g, s = qloss.grad(pb["theta"], as_pytree=False)
+    assert np.abs(r0["g"] - g).max() < 1e-10 * max(1.0, np.abs(g).max())
+    assert np.abs(r0["s"] - s).max() < 1e-11 * max(1.0, np.abs(s).max())
+    assert 0.0 <= float(r0["rate"]) <= 1.0

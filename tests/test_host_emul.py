@@ -1,0 +1,65 @@
+"""CPU checks of the KERNEL ARITHMETIC: coulombgas_amd/csrc/*.hpp compiled for the host (1-thread workgroup shim,
+tests/host_emul) against the committed golden vectors and the oracle.  The same comparisons run on the real
+GPU build in tests/test_gpu_golden.py."""
+import numpy as np
+import pytest
+
+from tests.common import GOLDEN
+from tests.emul_engine import EmulEngine
+
+
+def check_against_golden(eng_factory, name, tol=1e-10, exact=True):
+    g = np.load(GOLDEN + "/" + name)
+    n, dim, hs, ht, L = int(g["n"]), int(g["dim"]), int(g["spsize"]), int(g["tpsize"]), float(g["L"])
+    eng = eng_factory(n, dim, 2, hs, ht, L, g["sp_indices"])
+    eng.set_params(g["theta"])
+    x, s, v = g["x"], g["state_idx"], g["v"]
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    assert rel(eng.flow_forward(x), g["z"]) < tol
+    assert rel(eng.flow_jacobian(x), g["J"]) < tol
+    lphi, hld = eng.logphi_logjacdet(x, s)
+    assert rel(hld, g["half_logdetJ"]) < tol and rel(lphi[:, 0], g["logphi"][:, 0]) < tol
+    assert np.abs(np.angle(np.exp(1j * (lphi[:, 1] - g["logphi"][:, 1])))).max() < tol
+    if exact and "grad" in g:
+        gr, lp = eng.grad_laplacian(x, s, 0)
+        assert rel(gr, g["grad"]) < tol and rel(lp, g["lap_exact"]) < 10 * tol
+    gr, lp = eng.grad_laplacian(x, s, 1, v)
+    assert rel(gr, g["grad_hutch"]) < tol and rel(lp, g["lap_hutch"]) < 10 * tol
+    gr, lp = eng.grad_laplacian(x, s, 2, v)
+    assert rel(gr, g["grad_split"]) < tol and rel(lp, g["lap_split"]) < 10 * tol
+    eng.set_ewald(float(g["kappa"]), g["G"], float(g["rs"]))
+    assert rel(eng.ewald(x), g["V"]) < tol
+    assert rel(eng.param_vjp(x, s, g["w_re"], g["w_im"]), g["vjp"]) < tol
+    xm, lpm, nacc = eng.mcmc(x, s, 5, float(g["mc_stddev"]), noise=g["mc_noise"], unif=g["mc_unif"])
+    assert nacc / (5 * x.shape[0]) == pytest.approx(float(g["mc_rate"]), abs=1e-15)
+    assert np.abs(xm - g["mc_x"]).max() < 1e-12 and rel(lpm, g["mc_logp"]) < tol
+
+
+@pytest.mark.parametrize("name", ["golden_n7_d3.npz", "golden_n13_d2.npz", "golden_n29_d2.npz"])
+def test_device_code_on_host_vs_golden(name):
+    check_against_golden(EmulEngine, name)
+
+
+def test_symmetries_through_device_code():
+    """tests/test_flow.py:25,32,38 and tests/test_logpsi.py:45,54,72,77 restated on the device code (depth 2)."""
+    from tests.common import orbitals, flow_theta, state_indices
+    n, dim, L = 7, 3, 1.234
+    rng = np.random.default_rng(0)
+    sp = orbitals(3)
+    eng = EmulEngine(n, dim, 2, 16, 16, L, sp)
+    eng.set_params(flow_theta(rng, 2, 16, 16, dim, 0.3, 0.2))
+    x = rng.uniform(0, L, (n, dim))
+    s = state_indices(rng, 1, n, sp.shape[0])[0]
+    z = eng.flow_forward(x)
+    image = rng.integers(-5, 6, size=(n, dim)) * L
+    shift = rng.standard_normal(dim)
+    P = rng.permutation(n)
+    assert np.allclose(eng.flow_forward(x + image), z + image, atol=1e-10)
+    assert np.allclose(eng.flow_forward(x + shift), z + shift, atol=1e-10)
+    assert np.allclose(eng.flow_forward(x[P]), z[P], atol=1e-12)
+    a = eng.logpsi(x, s)
+    assert np.allclose(eng.logpsi(x + image, s)[0], a[0], atol=1e-9)
+    bP = eng.logpsi(x[P], s)
+    pa, pb = np.exp(a[0] + 1j * a[1]), np.exp(bP[0] + 1j * bP[1])
+    assert np.allclose(pb, pa) or np.allclose(pb, -pa)
+    assert np.allclose(eng.logp(x + shift, s), eng.logp(x, s), atol=1e-9)

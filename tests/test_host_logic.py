@@ -1,0 +1,135 @@
+"""Host-side logic of the reference-API mirror (CPU; the GPU engine is replaced by the host emulation of the
+device code, tests/emul_engine.py)."""
+import numpy as np
+import pytest
+import torch
+
+import coulombgas_amd as cg
+from coulombgas_amd import flow as fl, vmc
+from oracle import cg_ref as R
+from tests import emul_engine
+from tests.common import orbitals, box_length, flow_theta, state_indices, walkers, GOLDEN
+
+
+def test_parameter_tree_matches_haiku_layout():
+    """names, shapes, ravel order, P = 1074 for depth 2 / 16 / 16 / dim 2."""
+    order = fl.ravel_order(2, 16, 16, 2)
+    assert [(n, l, s) for n, l, s in order] == [
+        ("fermi_net/linear", "b", (2,)), ("fermi_net/linear", "w", (16, 2)),
+        ("fermi_net/~/linear", "b", (16,)), ("fermi_net/~/linear", "w", (9, 16)),
+        ("fermi_net/~/linear_1", "b", (16,)), ("fermi_net/~/linear_1", "w", (48, 16)),
+        ("fermi_net/~/linear_2", "b", (16,)), ("fermi_net/~/linear_2", "w", (5, 16))]
+    assert sum(int(np.prod(s)) for _, _, s in order) == 1074
+    f = cg.FermiNet(2, 16, 16, 9.5)
+    p = f.init(0, np.zeros((29, 2)))
+    th = f.ravel(p, 2)
+    assert th.shape == (1074,) and np.all(p["fermi_net/linear"]["b"] == 0) and 0.005 < p["fermi_net/~/linear_1"]["w"].std() < 0.02
+    q = f.unravel(th, 2)
+    assert all(np.array_equal(q[n][l], p[n][l]) for n, l, _ in order)
+    shipped = np.load(GOLDEN + "/shipped_n29_rs10.npz")["theta"]
+    assert f.unravel(shipped, 2)["fermi_net/~/linear_2"]["w"].shape == (5, 16)
+    with pytest.raises(ValueError):
+        cg.FermiNet(1, 16, 16, 1.0)
+    # same ordering as the oracle's restatement of ravel_pytree
+    assert [(n, l) for n, l, _ in order] == [(n, l) for n, l, _ in R.flow_ravel_order(2, 16, 16, 2)]
+    assert [(n, l) for n, l, _ in fl.ravel_order(3, 16, 16, 3)] == [(n, l) for n, l, _ in R.flow_ravel_order(3, 16, 16, 3)]
+
+
+def test_complex_clip_is_lexicographic():
+    """SURVEY App. B4 (src/VMC.py:73)"""
+    a = np.array([1 + 5j, -3 + 2j, 4 - 1j, 0.5 + 0j, 2 + 7j, -1 - 7j])
+    out = vmc.complex_clip(a, -1.0, 2.0)
+    assert np.array_equal(out, np.array([1 + 5j, -1 + 0j, 2 + 0j, 0.5 + 0j, 2 + 0j, -1 + 0j]))
+    ref = R.complex_clip(torch.as_tensor(a), -1.0, 2.0).numpy()
+    assert np.array_equal(out, ref)
+
+
+def test_kpoints_madelung_shard():
+    G = cg.kpoints(2, 15)
+    assert G.shape == (708, 2) and np.array_equal(G, R.kpoints(2, 15))
+    assert cg.kpoints(3, 4).shape[1] == 3
+    assert cg.Madelung(2, 10, G) == pytest.approx(-3.900264920056, abs=1e-11)
+    assert cg.Madelung(3, 7, cg.kpoints(3, 7)) == pytest.approx(R.Madelung(3, 7, R.kpoints(3, 7)), rel=1e-13)
+    x = np.arange(24.0).reshape(2, 3, 4)
+    assert np.array_equal(cg.shard(x, rank=1, world=2), x[1])
+    with pytest.raises(ValueError):
+        cg.shard(x, rank=0, world=4)
+    assert cg.replicate({"a": 1}, 8) == {"a": 1}
+
+
+def _problem(B=6, seed=17):
+    n, dim, hs, ht = 13, 2, 16, 16
+    L = box_length(n, dim)
+    rng = np.random.default_rng(seed)
+    sp = orbitals(2)
+    theta = flow_theta(rng, 2, hs, ht, dim, 0.1, 0.05)
+    return dict(n=n, dim=dim, hs=hs, ht=ht, L=L, sp=sp, theta=theta, x=walkers(rng, B, n, dim, L),
+                sidx=state_indices(rng, B, n, sp.shape[0]), rng=rng, rs=10.0, kappa=10, beta=1 / (4 * 0.15),
+                logp_states=-5.0 + rng.standard_normal(B), v=rng.standard_normal((B, n, dim)))
+
+
+def build_loss(pb, comm=None):
+    flow = cg.FermiNet(2, pb["hs"], pb["ht"], pb["L"])
+    G = cg.kpoints(pb["dim"], 15)
+    Vconst = pb["n"] * pb["rs"] / pb["L"] * cg.Madelung(pb["dim"], pb["kappa"], G)
+    logpsi_novmap = cg.make_logpsi(flow, pb["sp"], pb["L"])
+    logphi, logjacdet = cg.make_logphi_logjacdet(flow, pb["sp"], pb["L"])
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi_novmap, hutchinson=True, logphi=logphi, logjacdet=logjacdet)
+    return cg.make_loss(lambda pv, si: pv, logpsi, lgl, pb["kappa"], G, pb["L"], pb["rs"], Vconst, pb["beta"], comm=comm), G, Vconst
+
+
+def test_make_loss_host_algebra(monkeypatch):
+    """src/VMC.py:31-80 + main.py:277-278 with the emulated engine: observables, clip, values, gradients vs the oracle."""
+    emul_engine.install(monkeypatch)
+    pb = _problem()
+    obs_fn, G, Vconst = build_loss(pb)
+    obs, closs, qloss = obs_fn(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"])
+    qv = qloss(pb["theta"]); cv = closs(pb["logp_states"])
+    g_grad, g_score = qloss.grad(pb["theta"], as_pytree=False)
+    n, dim, hs, ht, L = pb["n"], pb["dim"], pb["hs"], pb["ht"], pb["L"]
+    rflow = R.FermiNet(2, hs, ht, L); rparams = R.flow_unravel(R.T(pb["theta"]), 2, hs, ht, dim)
+    r_logpsi = R.make_logpsi(rflow, pb["sp"], L)
+    r_logphi, r_logjacdet = R.make_logphi_logjacdet(rflow, pb["sp"], L)
+    _, rfn = R.make_logpsi_grad_laplacian(r_logpsi, hutchinson=True, logphi=r_logphi, logjacdet=r_logjacdet)
+    sb = torch.as_tensor(pb["sidx"].astype(np.int64))
+    gr, lr = rfn(R.T(pb["x"]), rparams, sb, R.T(pb["v"]))
+    pot = R.potential_energy(R.T(pb["x"]), pb["kappa"], G, L, pb["rs"])
+    robs, Eloc, Floc, Fc, Ec = R.observables_and_weights(R.T(pb["logp_states"]), gr, lr, pot, Vconst, pb["beta"])
+    assert set(obs) == set(robs)
+    for k in robs:
+        assert obs[k] == pytest.approx(float(robs[k]), rel=1e-9, abs=1e-9), k
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, 2, hs, ht, dim), sbb)
+    v0, v1, dg, ds = R.quantum_loss_and_grads(lpt, R.T(pb["theta"]), R.T(pb["x"]), sb, Ec)
+    assert qv[0] == pytest.approx(float(v0), rel=1e-9, abs=1e-9) and qv[1] == pytest.approx(float(v1), rel=1e-10)
+    assert np.abs(g_grad - dg.numpy()).max() < 1e-9 * max(1.0, np.abs(dg.numpy()).max())
+    assert np.abs(g_score - ds.numpy()).max() < 1e-10 * max(1.0, np.abs(ds.numpy()).max())
+    assert cv[0] == pytest.approx(float((R.T(pb["logp_states"]) * Fc).mean()), rel=1e-10)
+    assert np.allclose(closs.weights, Fc.numpy() / len(Fc))
+    tree_g, tree_s = qloss.grad(pb["theta"])
+    assert tree_g["fermi_net/~/linear_1"]["w"].shape == (48, 16)
+    only = cg.make_observable(lambda pv, si: pv, *[None] * 0, **{}) if False else None   # alias exists
+    assert callable(cg.make_observable)
+
+
+def test_sample_stateindices_and_x(monkeypatch):
+    """src/VMC.py:8-25: key split, sampler call, chain, wrap into [0, L)."""
+    emul_engine.install(monkeypatch)
+    pb = _problem(B=8)
+    flow = cg.FermiNet(2, 16, 16, pb["L"])
+    logp = cg.make_logp(cg.make_logpsi(flow, pb["sp"], pb["L"]))
+    calls = {}
+
+    def sampler(params_van, key_state, batch):
+        calls["batch"] = batch; calls["key"] = key_state
+        return pb["sidx"][:batch]
+    key = np.random.SeedSequence(42)
+    key2, s, x, rate = cg.sample_stateindices_and_x(key, sampler, None, logp, pb["x"] + 3 * pb["L"], pb["theta"], 5, 0.1, pb["L"])
+    assert calls["batch"] == 8 and isinstance(key2, np.random.SeedSequence)
+    assert s.dtype == np.int32 and s.shape == (8, 13) and x.shape == (8, 13, 2)
+    assert (x >= 0).all() and (x < pb["L"]).all() and 0.0 <= rate <= 1.0
+    # deterministic in the key
+    _, _, x_again, rate_again = cg.sample_stateindices_and_x(np.random.SeedSequence(42), sampler, None, logp, pb["x"] + 3 * pb["L"],
+                                                             pb["theta"], 5, 0.1, pb["L"])
+    assert np.array_equal(x, x_again) and rate == rate_again
+    with pytest.raises(TypeError):
+        cg.mcmc(lambda xx: xx, pb["x"], 0, 3, 0.1)          # an opaque callable cannot run in the GPU chain: no fallback
