@@ -48,9 +48,12 @@ class RcclComm:
         if unique_id is None:
             if rank == 0:
                 check(lib().cg_comm_unique_id(uid), None)
-            if exchange is None:
-                exchange = _torch_broadcast_bytes
-            raw = exchange(bytes(uid.raw) if rank == 0 else None)
+            if world == 1:
+                raw = bytes(uid.raw)
+            else:
+                if exchange is None:
+                    exchange = _torch_broadcast_bytes
+                raw = exchange(bytes(uid.raw) if rank == 0 else None)
             uid = (C.c_char * 128).from_buffer_copy(raw)
         else:
             uid = (C.c_char * 128).from_buffer_copy(unique_id)

@@ -279,3 +279,15 @@ def test_make_loss_against_oracle():
     # main.py:295-298 final-step combination stays host algebra: grad - <E> score
     final = g_grad - obs["E_mean"] * g_score
     assert np.isfinite(final).all()
+
+
+def test_rccl_allreduce_world1():
+    """RCCL plumbing (dlopen, communicator on the library's stream, sum + 1/N scale) with a 1-rank communicator."""
+    from coulombgas_amd.comm import RcclComm
+    s = _setup(CASES[0], 1)
+    eng = s["flow"].engine(13, 2, s["sp"])
+    comm = RcclComm(eng, 0, 1)
+    a = np.arange(37, dtype=np.float64) * 0.25
+    assert np.array_equal(comm.pmean(a), a)
+    assert comm.pmean(3.5) == 3.5
+    comm.close()
