@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcoulombgas_hip.so")
+LIB_PATH = os.environ.get("COULOMBGAS_HIP_LIB", os.path.join(_HERE, "lib", "libcoulombgas_hip.so"))   # override: A/B builds of the same ABI
 
 CG_OK, CG_ERR_ARG, CG_ERR_HIP, CG_ERR_UNSUPPORTED, CG_ERR_STATE, CG_ERR_RCCL = 0, -1, -2, -3, -4, -5
 CG_PTR_HOST, CG_PTR_DEVICE = 0, 1

@@ -322,22 +322,40 @@ struct CgFast {
     }
 };
 
-// host-side layout of the LDS arena (no aliasing beyond Dm <- {U,V,Bm,Up,G} region when `alias_D` is set)
-static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias_D) {
+// host-side layout of the LDS arena.
+//   alias = false: every array has its own slot (derivative kernels keep all intermediates for the reverse pass).
+//   alias = true : sampler layout.  Lifetimes inside CgFast::logpsi:
+//       persistent      sh ch z sg1 sg2 perm
+//       primal only     m0 s1 m1 gbar cb s2           (dead once z is formed)        -> share a slot with V Bm Up G
+//       jacobian        U (dead once Up is formed)                                    -> lives inside J
+//                       V Bm Up G J
+//       Slater matrix   Dm: after the LU of J                                          -> on top of V Bm Up G, or on J
+static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias) {
     CgFastLds o; int P = 2 * D + 1, t = 0;
     auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
     o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
-    o.m0 = take(n * P); o.s1 = take(n * HS); o.sg1 = take(n * HS); o.m1 = take(n * HT);
-    o.gbar = take(HS); o.cb = take(HS); o.sg2 = take(n * HS); o.s2 = take(n * HS);
-    int reg = t;
-    o.U = take(n * D * HS); o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P);
-    o.G = take(n * HS * D);
-    int reg_end = t;
-    o.J = take(n * D * n * D);
-    if (alias_D && (reg_end - reg) >= 2 * n * n) { o.Dm = reg; }
-    else if (alias_D) { o.Dm = o.J; }       // large n: Slater matrix reuses J after its LU
-    else o.Dm = take(2 * n * n);
+    o.sg1 = take(n * HS); o.sg2 = take(n * HS);
     o.perm = take((n * D + 1) / 2 + 1);
+    if (!alias) {
+        o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
+        o.U = take(n * D * HS); o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P); o.G = take(n * HS * D);
+        o.J = take(n * D * n * D);
+        o.Dm = take(2 * n * n);
+        o.total = t;
+        return o;
+    }
+    const int base = t;
+    o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
+    const int end_primal = t;
+    t = base;
+    o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P); o.G = take(n * HS * D);
+    const int end_jac = t;
+    t = end_primal > end_jac ? end_primal : end_jac;
+    o.J = take(n * D * n * D);
+    o.U = o.J;                                          // n*D*HS <= (n*D)^2 whenever HS <= n*D
+    if (n * D * HS > n * D * n * D) { o.U = take(n * D * HS); }
+    if (end_jac - base >= 2 * n * n) o.Dm = base;       // Slater matrix over the dead per-particle factors
+    else o.Dm = o.J;                                    // large n: over J after its LU (2 n^2 <= (n D)^2)
     o.total = t;
     return o;
 }

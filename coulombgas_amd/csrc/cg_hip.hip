@@ -22,8 +22,6 @@
 // device-side model descriptor (passed by value to every kernel)
 // ------------------------------------------------------------------------------------------
 struct CgDev {
-    const double* theta;   // P
-    const double* spk;     // M x D, already multiplied by 2 pi / L
     int n;
     double L;
     CgFastLds lay;
@@ -32,7 +30,7 @@ struct CgDev {
 enum { CG_MODE_LOGPSI = 0, CG_MODE_FLOW = 1, CG_MODE_JAC = 2 };
 
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                          double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
                          double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out) {
     using F = CgFast<D, HS, HT>;
@@ -45,7 +43,7 @@ __global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restri
         b.sync();
         if (mode == CG_MODE_LOGPSI) {
             double re, im, h;
-            F::logpsi(b, m.theta, xs, m.spk, sidx + (size_t)w * n, n, m.L, lds, m.lay, re, im, h);
+            F::logpsi(b, theta, xs, spk, sidx + (size_t)w * n, n, m.L, lds, m.lay, re, im, h);
             if (b.tid == 0) {
                 if (logphi) { logphi[2 * w] = re; logphi[2 * w + 1] = im; }
                 if (hld) hld[w] = h;
@@ -53,11 +51,11 @@ __global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restri
                 if (logp_out) logp_out[w] = 2.0 * (re + h);
             }
         } else {
-            F::primal(b, m.theta, xs, n, m.L, lds, m.lay);
+            F::primal(b, theta, xs, n, m.L, lds, m.lay);
             if (z_out)
                 for (int e = b.tid; e < N; e += b.nthr) z_out[(size_t)w * N + e] = lds[m.lay.z + e];
             if (mode == CG_MODE_JAC) {
-                F::jacobian(b, m.theta, n, m.L, lds, m.lay);
+                F::jacobian(b, theta, n, m.L, lds, m.lay);
                 for (int e = b.tid; e < N * N; e += b.nthr) J_out[(size_t)w * N * N + e] = lds[m.lay.J + e];
             }
         }
@@ -68,7 +66,7 @@ __global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restri
 // Batched Metropolis chain: src/MCMC.py:22-39.  One workgroup owns one walker for all mc_steps;
 // x is read once and written once, the proposal/accept state never leaves the CU.
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
+__global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
                        uint64_t seed, uint64_t walker_offset, const double* __restrict__ noise,
                        const double* __restrict__ unif, double* __restrict__ logp_out,
                        unsigned long long* __restrict__ n_accept) {
@@ -84,7 +82,7 @@ __global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, double* __restrict__ x, 
         for (int e = b.tid; e < N; e += b.nthr) xc[e] = x[(size_t)w * N + e];
         b.sync();
         double re, im, h;
-        F::logpsi(b, m.theta, xc, m.spk, si, n, m.L, lds, m.lay, re, im, h);
+        F::logpsi(b, theta, xc, spk, si, n, m.L, lds, m.lay, re, im, h);
         double logp = 2.0 * (re + h);
         unsigned int nacc = 0;
         for (int s = 0; s < steps; ++s) {
@@ -94,7 +92,7 @@ __global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, double* __restrict__ x, 
                 xp[e] = xc[e] + stddev * g;
             }
             b.sync();
-            F::logpsi(b, m.theta, xp, m.spk, si, n, m.L, lds, m.lay, re, im, h);
+            F::logpsi(b, theta, xp, spk, si, n, m.L, lds, m.lay, re, im, h);
             const double lp = 2.0 * (re + h);
             if (b.tid == 0) {
                 const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
@@ -143,14 +141,14 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 
 // grad / Laplacian of log Psi w.r.t. x (cg_derivs.hpp); per-walker workspace in HBM.
 template <int D, int HS, int HT>
-__global__ void k_grad_lap(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
                            double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     extern __shared__ double lds[];
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     const int n = m.n, N = n * D;
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
-        CgDerivs<D, HS, HT>::grad_laplacian(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L, mode,
+        CgDerivs<D, HS, HT>::grad_laplacian(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
                                             v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
                                             ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
         b.sync();
@@ -158,7 +156,7 @@ __global__ void k_grad_lap(CgDev m, const double* __restrict__ x, const int* __r
 }
 
 template <int D, int HS, int HT>
-__global__ void k_param_vjp(CgDev m, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+__global__ void k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
                             double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
@@ -170,7 +168,7 @@ __global__ void k_param_vjp(CgDev m, const double* __restrict__ x, const int* __
     if (gacc) for (int e = b.tid; e < P; e += b.nthr) gacc[e] = 0.0;
     b.sync();
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
-        CgDerivs<D, HS, HT>::param_vjp(b, m.theta, x + (size_t)w * N, m.spk, sidx + (size_t)w * n, n, m.L,
+        CgDerivs<D, HS, HT>::param_vjp(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L,
                                        w_re ? w_re[w] : 1.0, w_im ? w_im[w] : 0.0, gacc,
                                        score ? score + (size_t)w * P * 2 : nullptr,
                                        ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
@@ -330,7 +328,7 @@ static int auto_threads(int n) {
 static int threads_of(const cg_ctx* c) { return c->block_threads > 0 ? c->block_threads : auto_threads(c->n); }
 
 static CgDev make_dev(const cg_ctx* c) {
-    CgDev m; m.theta = c->d_theta; m.spk = c->d_spk; m.n = c->n; m.L = c->L; m.lay = c->lay;
+    CgDev m; m.n = c->n; m.L = c->L; m.lay = c->lay;
     return m;
 }
 
@@ -550,12 +548,12 @@ static int run_logpsi(cg_ctx* c, const char* fn, const double* x, const int32_t*
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
         if (nt <= 256) {                                                                                             \
             if ((rc = set_lds(c, k_logpsi<D, HS, HT, 256>, lds))) return rc;                                         \
-            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
                                (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
                                (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
         } else {                                                                                                     \
             if ((rc = set_lds(c, k_logpsi<D, HS, HT, 1024>, lds))) return rc;                                        \
-            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
                                (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
                                (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
         }                                                                                                            \
@@ -614,12 +612,12 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                  \
         if (nt <= 256) {                                                                                            \
             if ((rc = set_lds(c, k_mcmc<D, HS, HT, 256>, lds))) return rc;                                          \
-            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (double*)ax.dev,     \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (double*)ax.dev,     \
                                (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
                                (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
         } else {                                                                                                    \
             if ((rc = set_lds(c, k_mcmc<D, HS, HT, 1024>, lds))) return rc;                                         \
-            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (double*)ax.dev,    \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (double*)ax.dev,    \
                                (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
                                (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
         }                                                                                                           \
@@ -721,7 +719,7 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
         const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                            \
         if ((rc = set_lds(c, k_grad_lap<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
                            (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev,    \
                            (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                                    \
         launched = true;                                                                                            \
@@ -764,7 +762,7 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
         const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                 \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
         if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)ax.dev, \
+        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
                            (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
                            (double*)asc.dev, (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                   \
         launched = true;                                                                                             \
