@@ -31,6 +31,7 @@
 // Offsets (in doubles) into the per-walker LDS arena; filled by the host (cg_layout.hpp).
 struct CgFastLds {
     int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, total;
+    int wave_lu;      // 1: both determinants by the wave-level register LU (N <= 32, n <= 16, Dm not on J)
 };
 
 template <int D, int HS, int HT>
@@ -313,10 +314,33 @@ struct CgFast {
         primal(b, th, x, n, L, lds, o);
         jacobian(b, th, n, L, lds, o);
         int* perm = (int*)(lds + o.perm);
-        half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
-        slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
         double la, ar;
-        cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (o.wave_lu) {
+            // Slater matrix first (its slot does not overlap J), then the two LUs run barrier-free in registers:
+            // wave 0 the real Jacobian, wave 1 (if the workgroup has one) the complex Slater matrix, concurrently.
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            double* res = (double*)perm;
+            const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
+            if (wave == 0) {
+                const double v = cg_wave_lu_logabsdet<32>(lds + o.J, n * D, n * D);
+                if (b.tid == 0) res[0] = v;
+            }
+            if (wave == cw) {
+                double l2, a2;
+                cg_wave_lu_logdet_complex<16>(lds + o.Dm, n, n, l2, a2);
+                if ((b.tid & 63) == 0) { res[1] = l2; res[2] = a2; }
+            }
+            b.sync();
+            half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
+            b.sync();
+        } else
+#endif
+        {
+            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+        }
         re_phi = la - (double)n * (0.5 * D) * log(L);
         im_phi = ar;
     }
@@ -342,6 +366,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
         o.J = take(n * D * n * D);
         o.Dm = take(2 * n * n);
         o.total = t;
+        o.wave_lu = (n * D <= 32 && n <= 16) ? 1 : 0;
         return o;
     }
     const int base = t;
@@ -356,6 +381,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
     if (n * D * HS > n * D * n * D) { o.U = take(n * D * HS); }
     if (end_jac - base >= 2 * n * n) o.Dm = base;       // Slater matrix over the dead per-particle factors
     else o.Dm = o.J;                                    // large n: over J after its LU (2 n^2 <= (n D)^2)
+    o.wave_lu = (n * D <= 32 && n <= 16 && o.Dm != o.J && (n * D + 1) / 2 + 1 >= 3) ? 1 : 0;
     o.total = t;
     return o;
 }

@@ -27,10 +27,15 @@ struct CgDev {
     CgFastLds lay;
 };
 
+// minimum waves per SIMD the sampler kernels are register-allocated for (2 -> <= 256 VGPRs, 4 -> <= 128)
+#ifndef CG_WAVES_PER_EU
+#define CG_WAVES_PER_EU 2
+#endif
+
 enum { CG_MODE_LOGPSI = 0, CG_MODE_FLOW = 1, CG_MODE_JAC = 2 };
 
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_logpsi(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                          double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
                          double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out) {
     using F = CgFast<D, HS, HT>;
@@ -66,7 +71,7 @@ __global__ void __launch_bounds__(MAXT) k_logpsi(CgDev m, const double* __restri
 // Batched Metropolis chain: src/MCMC.py:22-39.  One workgroup owns one walker for all mc_steps;
 // x is read once and written once, the proposal/accept state never leaves the CU.
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
                        uint64_t seed, uint64_t walker_offset, const double* __restrict__ noise,
                        const double* __restrict__ unif, double* __restrict__ logp_out,
                        unsigned long long* __restrict__ n_accept) {

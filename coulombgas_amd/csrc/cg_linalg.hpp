@@ -195,3 +195,110 @@ CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, doubl
     logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
     arg = atan2(pm.im, pm.re);
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-level register LU (gfx950 only): one wave64 factorises one small matrix held one ROW PER LANE in VGPRs.
+// No LDS traffic, no barriers: the pivot row is broadcast with v_readlane (the pivot lane index is wave-uniform),
+// rows are never swapped (a lane that has served as pivot just stops updating), the pivot search is a DPP max on
+// the high word of |a_ik| (a near-maximal pivot is as good as the maximal one) + ballot.
+// Used by the sampler for N = n*d <= 32 (real Jacobian) and n <= 16 (complex Slater matrix).
+// ------------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double cg_readlane_f64(double v, int lane) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, lane);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// wave-uniform maximum of an unsigned key (DPP row reduction + 4 readlanes)
+__device__ __forceinline__ unsigned cg_wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+    const unsigned a = __builtin_amdgcn_readlane((int)v, 15), b = __builtin_amdgcn_readlane((int)v, 31),
+                   c = __builtin_amdgcn_readlane((int)v, 47), d = __builtin_amdgcn_readlane((int)v, 63);
+    return max(max(a, b), max(c, d));
+}
+
+// log|det A|, A: N x N real in LDS (row-major, lda).  Must be called by all 64 lanes of ONE wave.
+template <int NMAX>
+__device__ __forceinline__ double cg_wave_lu_logabsdet(const double* A, int N, int lda) {
+    const int lane = threadIdx.x & 63;
+    double a[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) a[j] = (lane < N && j < N) ? A[lane * lda + j] : 0.0;
+    bool done = lane >= N;
+    CgScaledProd prod; prod.init();
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < N) {
+            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(a[k])) >> 32) + 1u;
+            const unsigned mx = cg_wave_max_u32(key);
+            const unsigned long long mask = __ballot(key == mx && !done);
+            const int p = mask ? (int)__builtin_ctzll(mask) : k;        // singular column: any row (pivot 0 -> -inf)
+            const double piv = cg_readlane_f64(a[k], p);
+            prod.mul(piv);
+            const double rinv = 1.0 / piv;
+            const double l = (done || lane == p) ? 0.0 : a[k] * rinv;
+#pragma unroll
+            for (int j = k + 1; j < NMAX; ++j) {
+                const double pr = cg_readlane_f64(a[j], p);
+                a[j] = fma(-l, pr, a[j]);
+            }
+            done = done || (lane == p);
+        }
+    }
+    return prod.logabs();
+}
+
+// complex version: A interleaved (re,im) N x N in LDS; returns log|det| and arg(det) including the permutation sign
+template <int NMAX>
+__device__ __forceinline__ void cg_wave_lu_logdet_complex(const double* A, int N, int lda, double& logabs, double& arg) {
+    const int lane = threadIdx.x & 63;
+    double ar[NMAX], ai[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        const bool ok = lane < N && j < N;
+        ar[j] = ok ? A[2 * (lane * lda + j)] : 0.0;
+        ai[j] = ok ? A[2 * (lane * lda + j) + 1] : 0.0;
+    }
+    bool done = lane >= N;
+    int mypos = lane;                 // position of this row under the equivalent sequence of row swaps
+    int parity = 0;
+    CgCplx pm = {1.0, 0.0}; int pe = 0;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < N) {
+            const double m2 = ar[k] * ar[k] + ai[k] * ai[k];
+            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
+            const unsigned mx = cg_wave_max_u32(key);
+            const unsigned long long mask = __ballot(key == mx && !done);
+            const int p = mask ? (int)__builtin_ctzll(mask) : k;
+            const int posp = __builtin_amdgcn_readlane(mypos, p);
+            if (posp != k) {          // swap positions k <-> posp
+                parity ^= 1;
+                if (mypos == k) mypos = posp;
+                if (lane == p) mypos = k;
+            }
+            const CgCplx piv = {cg_readlane_f64(ar[k], p), cg_readlane_f64(ai[k], p)};
+            pm = cmul(pm, piv);
+            { int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
+              pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex; }
+            const CgCplx rinv = cinv(piv);
+            CgCplx l = cmul({ar[k], ai[k]}, rinv);
+            if (done || lane == p) { l.re = 0.0; l.im = 0.0; }
+#pragma unroll
+            for (int j = k + 1; j < NMAX; ++j) {
+                const double pr = cg_readlane_f64(ar[j], p), pi = cg_readlane_f64(ai[j], p);
+                ar[j] = fma(-l.re, pr, fma(l.im, pi, ar[j]));
+                ai[j] = fma(-l.re, pi, fma(-l.im, pr, ai[j]));
+            }
+            done = done || (lane == p);
+        }
+    }
+    if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
+    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = atan2(pm.im, pm.re);
+}
+#endif
