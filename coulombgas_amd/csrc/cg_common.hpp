@@ -9,6 +9,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -33,77 +34,103 @@ struct CgBlk {
 #define CG_PI 3.14159265358979323846264338327950288
 
 // ---- fp64 transcendentals specialised for the flow's activations ---------------------------------------------
-// gfx950 has no f64 exp/log instructions; the generic ocml routines carry range/special-case handling these
-// call sites do not need.  Accuracy of the pieces below is ~1 ulp (tests compare with libm through the oracle).
+// gfx950 has no f64 exp/log instructions.  The generic ocml routines carry range / special-case handling these
+// call sites do not need, and a plain polynomial evaluation costs ~65 VALU instructions per softplus.  The versions
+// below use two small tables (1.25 KB, staged in LDS by every kernel; plain memory on the host shim):
+//   exp2t[j] = 2^(j/32)                                   j = 0..31
+//   logt[i]  = { 1/c_i rounded, -log(1/c_i rounded) }      c_i = 1 + (i + 1/2)/64,  i = 0..63
+// e^x (x <= 0):  x = (32 m + j) ln2/32 + r, |r| <= ln2/64        -> 2^m exp2t[j] P6(r)
+// log w, 1/w (w in [1,2)):  r = w/c_i - 1, |r| <= 1/128          -> logt[i][1] + log1p(r) (degree 7), (1/c_i)(1-r)(1+r^2)(1+r^4)
+// Accuracy ~1-2 ulp (tests compare with libm through the oracle; the table is generated in long double).
+#define CG_TAB_DOUBLES 160
+static inline void cg_tab_fill(double* t) {
+    for (int j = 0; j < 32; ++j) t[j] = (double)exp2l((long double)j / 32.0L);
+    for (int i = 0; i < 64; ++i) {
+        const long double c = 1.0L + ((long double)i + 0.5L) / 64.0L;
+        const double inv = (double)(1.0L / c);
+        t[32 + 2 * i] = inv;
+        t[32 + 2 * i + 1] = (double)(-logl((long double)inv));
+    }
+}
+#if defined(__HIPCC__)
+extern __shared__ double cg_dyn_lds[];            // every kernel keeps the table in its first CG_TAB_DOUBLES of LDS
+#define CG_TAB (cg_dyn_lds)
+#else
+#if !defined(__HIPCC__)
+static inline const double* cg_host_tab() {
+    static double t[CG_TAB_DOUBLES]; static bool init = false;
+    if (!init) { cg_tab_fill(t); init = true; }
+    return t;
+}
+#define CG_TAB (cg_host_tab())
+#endif
+#endif
 
-// e^x for x <= 0 (x = -|u|).  k = rint(x log2 e), r = x - k ln2 (two-part), degree-13 Taylor, scale by 2^k.
+// e^x for x <= 0
 CG_DEVI double cg_exp_nonpos(double x) {
     x = fmax(x, -746.0);                                  // below this e^x underflows to 0 anyway
-    const double kf = rint(x * 1.4426950408889634074);
-    double r = fma(-kf, 6.93147180369123816490e-01, x);
-    r = fma(-kf, 1.90821492927058770002e-10, r);
-    double p = 1.6059043836821614599e-10;                 // 1/13!
-    p = fma(p, r, 2.0876756987868098979e-09);             // 1/12!
-    p = fma(p, r, 2.5052108385441718775e-08);             // 1/11!
-    p = fma(p, r, 2.7557319223985890653e-07);             // 1/10!
-    p = fma(p, r, 2.7557319223985892511e-06);             // 1/9!
-    p = fma(p, r, 2.4801587301587301566e-05);             // 1/8!
-    p = fma(p, r, 1.9841269841269841253e-04);             // 1/7!
-    p = fma(p, r, 1.3888888888888889419e-03);             // 1/6!
-    p = fma(p, r, 8.3333333333333332177e-03);             // 1/5!
-    p = fma(p, r, 4.1666666666666664354e-02);             // 1/4!
-    p = fma(p, r, 1.6666666666666665741e-01);             // 1/3!
+    const double kf = rint(x * 46.166241308446828384);    // 32 / ln 2
+    double r = fma(-kf, 2.16608493924982901946e-02, x);   // ln2/32 hi
+    r = fma(-kf, 7.24702129326968612006e-19, r);          // ln2/32 lo
+    const int ki = (int)kf;
+    const double tj = CG_TAB[ki & 31];
+    double p = 1.0 / 720.0;
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)kf);
+    return ldexp(tj * p, ki >> 5);
 }
-// 1/w.  IEEE division on purpose: a hand-rolled v_rcp_f64 + 2 Newton steps version produced a 1e-7 relative
-// deviation in one ill-conditioned parity case on gfx950 (every variant with a correctly rounded quotient in either
-// call site, or a third Newton step, did not) -- correctness first, ~4 instructions per call.
-CG_DEVI double cg_rcp_12(double w) { return 1.0 / w; }
-// log(w) for w in [1,2]:  m = w or w/2 in [sqrt(1/2), sqrt 2], s = (m-1)/(m+1), log m = 2 s (1 + s^2/3 + ... + s^20/21)
-CG_DEVI double cg_log_12(double w) {
-    const bool hi = w > 1.41421356237309514547;
-    const double m = hi ? 0.5 * w : w;
-    const double den = m + 1.0;                           // in [1.707, 2.414]
-    const double s = (m - 1.0) / den;
-    const double z = s * s;
-    double p = 1.0 / 21.0;
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = p * z;                                            // log m = 2s + 2s*p
-    const double two_s = s + s;
-    const double lg = fma(two_s, p, two_s);
-    return hi ? lg + 0.693147180559945309417232121458 : lg;
+// w in [1, 2]: returns log(w) and 1/w
+CG_DEVI void cg_log_rcp_12(double w, double& lg, double& rc) {
+    const bool two = w >= 2.0;                            // w = 1 + e^{-|u|} = 2 exactly when u = 0
+    const double m = two ? 1.0 : w;
+#if defined(__HIPCC__)
+    const int hi = __double2hiint(m);
+#else
+    long long bits; memcpy(&bits, &m, 8); const int hi = (int)(bits >> 32);
+#endif
+    const int i = (hi >> 14) & 63;                        // top 6 mantissa bits
+    const double inv = CG_TAB[32 + 2 * i], lc = CG_TAB[32 + 2 * i + 1];
+    const double r = fma(m, inv, -1.0);                   // |r| <= 1/128
+    double p = 1.0 / 7.0;
+    p = fma(p, r, -1.0 / 6.0);
+    p = fma(p, r, 0.2);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    const double l = fma(p, r, lc);                       // log c_i + log1p(r)
+    const double r2 = r * r;
+    double t = 1.0 - r;
+    t = fma(t, r2, t);
+    t = fma(t, r2 * r2, t);
+    const double q = inv * t;                             // 1/m
+    lg = two ? 0.693147180559945309417232121458 : l;
+    rc = two ? 0.5 : q;
 }
 // softplus(u) = log(1 + e^u) = max(u,0) + log1p(e^{-|u|}); sigmoid from the same exponential.
 // (jax.nn.softplus == logaddexp(u, 0): no large-u cut-off, reference src/flow.py:45-52)
 CG_DEVI void softplus_sigmoid(double u, double& sp, double& sg) {
     const double e = cg_exp_nonpos(-fabs(u));
     const double w = 1.0 + e;
-    const double r = cg_rcp_12(w);
+    double lg, r; cg_log_rcp_12(w, lg, r);
     // log1p(e) = log(w) + (e - (w - 1)) / w   (restores the bits of e lost in forming w)
-    sp = fmax(u, 0.0) + fma(e - (w - 1.0), r, cg_log_12(w));
+    sp = fmax(u, 0.0) + fma(e - (w - 1.0), r, lg);
     sg = (u >= 0.0) ? r : e * r;
 }
 CG_DEVI double sigmoid_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));
-    const double r = cg_rcp_12(1.0 + e);
+    double lg, r; cg_log_rcp_12(1.0 + e, lg, r);
     return (u >= 0.0) ? r : e * r;
 }
 CG_DEVI double softplus_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));
     const double w = 1.0 + e;
-    const double c = e - (w - 1.0);                        // |c| <= 2^-53; c / w ~ c (1 - e/2) to 1e-17
-    return fmax(u, 0.0) + fma(c, fma(-0.5, e, 1.0), cg_log_12(w));
+    double lg, r; cg_log_rcp_12(w, lg, r);
+    return fmax(u, 0.0) + fma(e - (w - 1.0), r, lg);
 }
 
 // running product with exponent kept apart (avoids n logs per determinant and over/underflow)

@@ -35,12 +35,14 @@ struct CgDev {
 enum { CG_MODE_LOGPSI = 0, CG_MODE_FLOW = 1, CG_MODE_JAC = 2 };
 
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_logpsi(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_logpsi(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                          double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
                          double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out) {
     using F = CgFast<D, HS, HT>;
-    extern __shared__ double lds[];
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
     const int n = m.n, N = n * D;
     double* xs = lds + m.lay.total;
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
@@ -71,13 +73,15 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_l
 // Batched Metropolis chain: src/MCMC.py:22-39.  One workgroup owns one walker for all mc_steps;
 // x is read once and written once, the proposal/accept state never leaves the CU.
 template <int D, int HS, int HT, int MAXT>
-__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
+__global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
                        uint64_t seed, uint64_t walker_offset, const double* __restrict__ noise,
                        const double* __restrict__ unif, double* __restrict__ logp_out,
                        unsigned long long* __restrict__ n_accept) {
     using F = CgFast<D, HS, HT>;
-    extern __shared__ double lds[];
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
     const int n = m.n, N = n * D;
     double* xc = lds + m.lay.total;          // current configuration
     double* xp = xc + ((N + 1) & ~1);        // proposal
@@ -146,11 +150,13 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 
 // grad / Laplacian of log Psi w.r.t. x (cg_derivs.hpp); per-walker workspace in HBM.
 template <int D, int HS, int HT>
-__global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
                            double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
-    extern __shared__ double lds[];
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
     const int n = m.n, N = n * D;
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
         CgDerivs<D, HS, HT>::grad_laplacian(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
@@ -161,12 +167,14 @@ __global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const doub
 }
 
 template <int D, int HS, int HT>
-__global__ void k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+__global__ void k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
                             double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
-    extern __shared__ double lds[];
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
     const int n = m.n, N = n * D;
     constexpr int P = CgFast<D, HS, HT>::NPARAM;
     double* gacc = partial ? partial + (size_t)blockIdx.x * P : nullptr;
@@ -239,6 +247,7 @@ struct cg_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double* d_theta = nullptr;
     double* d_spk = nullptr;
+    double* d_tab = nullptr;     // exp / log tables of cg_common.hpp
     bool have_theta = false;
     // ewald
     bool have_ewald = false;
@@ -382,6 +391,9 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
     if ((e = hipMalloc((void**)&c->d_theta, sizeof(double) * c->P)) != hipSuccess) return fail("hipMalloc theta", e);
     if ((e = hipMalloc((void**)&c->d_spk, sizeof(double) * (size_t)M * dim)) != hipSuccess) return fail("hipMalloc orbitals", e);
     if ((e = hipMalloc((void**)&c->d_accept, sizeof(unsigned long long))) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->d_tab, sizeof(double) * CG_TAB_DOUBLES)) != hipSuccess) return fail("hipMalloc tables", e);
+    { double tabh[CG_TAB_DOUBLES]; cg_tab_fill(tabh);
+      if ((e = hipMemcpy(c->d_tab, tabh, sizeof(tabh), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy tables", e); }
     std::vector<double> spk((size_t)M * dim);
     for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);     // src/slater.py:14
     if ((e = hipMemcpy(c->d_spk, spk.data(), sizeof(double) * spk.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy orbitals", e);
@@ -398,6 +410,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_spk) (void)hipFree(c->d_spk);
+    if (c->d_tab) (void)hipFree(c->d_tab);
     if (c->d_G) (void)hipFree(c->d_G);
     if (c->d_gk) (void)hipFree(c->d_gk);
     if (c->d_accept) (void)hipFree(c->d_accept);
@@ -515,7 +528,7 @@ int cg_get_launch_info(cg_ctx* c, int64_t* info) {
     if (!c || !info) return CG_ERR_ARG;
     const int N = c->n * c->dim;
     info[0] = threads_of(c);
-    info[1] = (int64_t)sizeof(double) * (c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    info[1] = (int64_t)sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
     info[2] = c->cu_count; info[3] = c->P; info[4] = c->fast ? 1 : 0; info[5] = info[6] = info[7] = 0;
     return CG_OK;
 }
@@ -546,19 +559,19 @@ static int run_logpsi(cg_ctx* c, const char* fn, const double* x, const int32_t*
     Arg* all[] = {&ax, &as, &a1, &a2, &a3, &a4, &a5, &a6};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
     const int nt = threads_of(c);
-    const size_t lds = sizeof(double) * (c->lay.total + ((N + 1) & ~1));
+    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + ((N + 1) & ~1));
     const CgDev m = make_dev(c);
     bool launched = false;
 #define CG_X(D, HS, HT)                                                                                              \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
         if (nt <= 256) {                                                                                             \
             if ((rc = set_lds(c, k_logpsi<D, HS, HT, 256>, lds))) return rc;                                         \
-            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
                                (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
                                (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
         } else {                                                                                                     \
             if ((rc = set_lds(c, k_logpsi<D, HS, HT, 1024>, lds))) return rc;                                        \
-            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
+            hipLaunchKernelGGL((k_logpsi<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
                                (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev,       \
                                (double*)a4.dev, (double*)a5.dev, (double*)a6.dev);                                   \
         }                                                                                                            \
@@ -610,19 +623,19 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
     CG_HIP(c, hipMemsetAsync(c->d_accept, 0, sizeof(unsigned long long), c->stream));
     const int nt = threads_of(c);
-    const size_t lds = sizeof(double) * (c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
     const CgDev m = make_dev(c);
     bool launched = false;
 #define CG_X(D, HS, HT)                                                                                             \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                  \
         if (nt <= 256) {                                                                                            \
             if ((rc = set_lds(c, k_mcmc<D, HS, HT, 256>, lds))) return rc;                                          \
-            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (double*)ax.dev,     \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 256>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (double*)ax.dev,     \
                                (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
                                (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
         } else {                                                                                                    \
             if ((rc = set_lds(c, k_mcmc<D, HS, HT, 1024>, lds))) return rc;                                         \
-            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (double*)ax.dev,    \
+            hipLaunchKernelGGL((k_mcmc<D, HS, HT, 1024>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (double*)ax.dev,    \
                                (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                     \
                                (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);         \
         }                                                                                                           \
@@ -721,10 +734,10 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 #define CG_X(D, HS, HT)                                                                                              \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                      \
-        const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt));                                \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                            \
         if ((rc = set_lds(c, k_grad_lap<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
+        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
                            (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev,    \
                            (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                                    \
         launched = true;                                                                                            \
@@ -764,10 +777,10 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
 #define CG_X(D, HS, HT)                                                                                               \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \
-        const size_t lds = sizeof(double) * CgDerivs<D, HS, HT>::lds_doubles(n, nt);                                 \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt));                                 \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
         if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)ax.dev, \
+        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
                            (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
                            (double*)asc.dev, (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                   \
         launched = true;                                                                                             \
