@@ -30,7 +30,7 @@
 
 // Offsets (in doubles) into the per-walker LDS arena; filled by the host (cg_layout.hpp).
 struct CgFastLds {
-    int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, total;
+    int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, wt, total;
     int wave_lu;      // 1: both determinants by the wave-level register LU (N <= 32, n <= 16, Dm not on J)
 };
 
@@ -74,12 +74,189 @@ struct CgFast {
         }
     }
 
+
+    // ---------------------------------------------------------------------------------------
+    // Dense layers on the matrix cores (gfx950, spsize = tpsize = 16, T = double only).
+    // The per-particle layers are tiny GEMMs against the flow weights: (n x 5)(5 x 16), (n x 48)(48 x 16),
+    // (n x 16)(16 x d), (n d x 16)(16 x 16) x 3, (n d x 16)(16 x 5).  As scalar loops each lane chases its own
+    // weight row through L1 (measured: ~45 % of a logp evaluation).  With v_mfma_f64_16x16x4_f64 the weight
+    // operand of every k-step is ONE double per lane, loaded once per kernel (WFrag) and kept in VGPRs for the
+    // whole Metropolis chain; activations are read from LDS in the A-operand layout.
+    //   A: lane l holds A[row = l & 15][k = l >> 4];  B: B[k = l >> 4][col = l & 15];
+    //   C/D: 4 doubles per lane, D[row = (l >> 4) + 4 r][col = l & 15]   (f64 layout, not the f32 one)
+    // ---------------------------------------------------------------------------------------
+    struct WFrag {
+        double w0[2];      // W0 (P x 16), K padded to 8
+        double b0, b2;     // biases of the two one-particle layers, by column
+        double wacb[12];   // [Wa; Wc; Wb] (48 x 16): u2 = s1 Wa + m1 Wc + gbar Wb
+        double wf[4];      // Wf (16 x D), columns >= D zero
+        double bf;         // final bias by column (0 beyond D)
+        double ja[4], jb[4], jc[4];   // Wa^T, Wb^T, Wc^T (k = h, col = g): R_i W_x^T
+        double w0t[4];     // W0^T (k = g, col = f < P)
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w) {
+        const int l = threadIdx.x & 63, col = l & 15, kq = l >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const int f = 4 * ks + kq; w.w0[ks] = f < P ? th[o_W0 + f * HS + col] : 0.0; }
+        w.b0 = th[o_s0b + col]; w.b2 = th[o_s1b + col];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + kq;
+            w.wacb[ks] = th[o_Wa + k * HS + col];
+            w.wacb[4 + ks] = th[o_Wc + k * HS + col];
+            w.wacb[8 + ks] = th[o_Wb + k * HS + col];
+            w.wf[ks] = col < D ? th[o_fw + k * D + col] : 0.0;
+            w.ja[ks] = th[o_Wa + col * HS + k];            // B[k = h][col = g] = Wa[g][h]
+            w.jb[ks] = th[o_Wb + col * HS + k];
+            w.jc[ks] = th[o_Wc + col * HS + k];
+            w.w0t[ks] = col < P ? th[o_W0 + col * HS + k] : 0.0;   // B[k = g][col = f] = W0[f][g]
+        }
+        w.bf = col < D ? th[o_fb + col] : 0.0;
+    }
+    // dense part of primal(): needs m0, m1 in LDS; fills s1 sg1 sg2 s2 z.  Executed by wave 0; others wait.
+    static __device__ __forceinline__ void primal_dense_mfma(const CgBlk& b, const WFrag& w, const double* x, int n,
+                                                             double* lds, const CgFastLds& o) {
+        double *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1, *m1 = lds + o.m1, *gbar = lds + o.gbar,
+               *sg2 = lds + o.sg2, *s2 = lds + o.s2, *z = lds + o.z;
+        const int l = b.tid & 63, col = l & 15, kq = l >> 4;
+        const int wave = b.tid >> 6, nw = b.nthr >> 6;
+        const int tiles = (n + 15) >> 4;
+        const double rn = 1.0 / (double)n;
+        // layer 0: u1 = m0 W0 + b0
+        for (int t = wave; t < tiles; t += nw) {
+            const int ia = 16 * t + col;                     // A row of this lane
+            d4_t c = {w.b0, w.b0, w.b0, w.b0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int f = 4 * ks + kq;
+                const double a = (ia < n && f < P) ? m0[ia * P + f] : 0.0;
+                c = mfma(a, w.w0[ks], c);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * t + kq + 4 * r;
+                if (i < n) { double sp, sg; softplus_sigmoid(c[r], sp, sg); s1[i * HS + col] = sp; sg1[i * HS + col] = sg; }
+            }
+        }
+        b.sync();
+        if (b.tid < HS) {                                     // gbar = mean_i s1_i
+            double a = 0.0;
+            for (int i = 0; i < n; ++i) a += s1[i * HS + b.tid];
+            gbar[b.tid] = a * rn;
+        }
+        b.sync();
+        // last layer: u2 = s1 Wa + m1 Wc + gbar Wb + b2;  s2 = s1 + softplus(u2)
+        for (int t = wave; t < tiles; t += nw) {
+            const int ia = 16 * t + col;
+            d4_t c = {w.b2, w.b2, w.b2, w.b2};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + kq;
+                const double a1 = ia < n ? s1[ia * HS + k] : 0.0;
+                const double a2 = ia < n ? m1[ia * HT + k] : 0.0;
+                const double a3 = ia < n ? gbar[k] : 0.0;
+                c = mfma(a1, w.wacb[ks], c);
+                c = mfma(a2, w.wacb[4 + ks], c);
+                c = mfma(a3, w.wacb[8 + ks], c);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * t + kq + 4 * r;
+                if (i < n) { double sp, sg; softplus_sigmoid(c[r], sp, sg); sg2[i * HS + col] = sg; s2[i * HS + col] = s1[i * HS + col] + sp; }
+            }
+        }
+        b.sync();
+        // z = x + s2 Wf + bf
+        for (int t = wave; t < tiles; t += nw) {
+            const int ia = 16 * t + col;
+            d4_t c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * t + kq + 4 * r;
+                c[r] = (i < n && col < D) ? x[i * D + col] + w.bf : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const double a = ia < n ? s2[ia * HS + 4 * ks + kq] : 0.0;
+                c = mfma(a, w.wf[ks], c);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * t + kq + 4 * r;
+                if (i < n && col < D) z[i * D + col] = c[r];
+            }
+        }
+        b.sync();
+    }
+    // U, Bm, V of jacobian(): rows r = (i,a).  wfl: Wf (HS x D) staged in LDS.
+    static __device__ __forceinline__ void jac_factors_mfma(const CgBlk& b, const WFrag& w, int n, double* lds,
+                                                            const CgFastLds& o, const double* wfl) {
+        const double* sg2 = lds + o.sg2;
+        double *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm;
+        const int l = b.tid & 63, col = l & 15, kq = l >> 4;
+        const int wave = b.tid >> 6, nw = b.nthr >> 6;
+        const int N = n * D, tiles = (N + 15) >> 4;
+        const double rn = 1.0 / (double)n;
+        for (int t = wave; t < tiles; t += nw) {
+            const int ra = 16 * t + col, ia = ra / D, aa = ra - ia * D;
+            d4_t cu, cbm = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + kq + 4 * r;
+                cu[r] = rr < N ? wfl[col * D + (rr % D)] : 0.0;      // direct term Wf[g][a]
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int h = 4 * ks + kq;
+                const double a = ra < N ? wfl[h * D + aa] * sg2[ia * HS + h] : 0.0;   // R_i[a][h]
+                cu = mfma(a, w.ja[ks], cu);
+                cbm = mfma(a, w.jb[ks], cbm);
+                cv = mfma(a, w.jc[ks], cv);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + kq + 4 * r;
+                if (rr < N) { U[rr * HS + col] = cu[r]; Bm[rr * HS + col] = cbm[r]; V[rr * HT + col] = cv[r] * rn; }
+            }
+        }
+    }
+    // Up = (1/n) (U diag sg1) W0^T
+    static __device__ __forceinline__ void jac_up_mfma(const CgBlk& b, const WFrag& w, int n, double* lds, const CgFastLds& o) {
+        const double *sg1 = lds + o.sg1, *U = lds + o.U;
+        double* Up = lds + o.Up;
+        const int l = b.tid & 63, col = l & 15, kq = l >> 4;
+        const int wave = b.tid >> 6, nw = b.nthr >> 6;
+        const int N = n * D, tiles = (N + 15) >> 4;
+        const double rn = 1.0 / (double)n;
+        for (int t = wave; t < tiles; t += nw) {
+            const int ra = 16 * t + col, ia = ra / D;
+            d4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int g = 4 * ks + kq;
+                const double a = ra < N ? U[ra * HS + g] * sg1[ia * HS + g] : 0.0;
+                c = mfma(a, w.w0t[ks], c);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + kq + 4 * r;
+                if (rr < N && col < P) Up[rr * P + col] = c[r] * rn;
+            }
+        }
+    }
+#endif
+
     // ---------------------------------------------------------------------------------------
     // primal pass: fills sh,ch,m0,s1,sg1,m1,gbar,cb,sg2,s2,z in LDS.
     // ---------------------------------------------------------------------------------------
     template <class T>
     static CG_DEVI void primal(const CgBlk& b, const double* __restrict__ th, const T* x /*n*D*/,
-                               int n, double L, T* lds, const CgFastLds& o) {
+                               int n, double L, T* lds, const CgFastLds& o, const WFrag* wf = nullptr) {
         T *sh = lds + o.sh, *ch = lds + o.ch, *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1,
                *m1 = lds + o.m1, *gbar = lds + o.gbar, *cb = lds + o.cb, *sg2 = lds + o.sg2, *s2 = lds + o.s2,
                *z = lds + o.z;
@@ -99,6 +276,7 @@ struct CgFast {
             for (int f = 0; f < P; ++f) wt[f] = do_t ? th[o_t0w + f * HT + h] : 0.0;
             if (do_t) bt = th[o_t0b + h];
             T acc = T(0.0), raw = T(0.0);
+#pragma unroll 2
             for (int j = 0; j < n; ++j) {
                 PairFT<T> pf; pairfeat(sh, ch, i, j, pf);
                 T u = T(bt);
@@ -117,6 +295,11 @@ struct CgFast {
             if (h < P) m0[i * P + h] = raw * rn;
         }
         b.sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) { primal_dense_mfma(b, *wf, (const double*)x, n, (double*)lds, o); return; }
+        }
+#endif
         // layer 0 of the one-particle stream: u1_i = W0^T m0_i + b0 (s0 = 0, src/flow.py:16-18,45)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int i = e / HS, h = e - i * HS;
@@ -167,13 +350,32 @@ struct CgFast {
     // ---------------------------------------------------------------------------------------
     template <class T>
     static CG_DEVI void jacobian(const CgBlk& b, const double* __restrict__ th, int n, double L,
-                                 T* lds, const CgFastLds& o) {
+                                 T* lds, const CgFastLds& o, const WFrag* wf = nullptr) {
         const T *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2;
         T *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up, *G = lds + o.G, *J = lds + o.J;
         const int N = n * D;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        // two-particle layer weights -> arena, [h][bias, w_0..w_{P-1}]: the Jacobian pass reads them with broadcast loads
+        double* wt = (double*)(lds + o.wt);
+        for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
+            const int h = e / (P + 1), f = e - h * (P + 1);
+            wt[e] = f == 0 ? th[o_t0b + h] : th[o_t0w + (f - 1) * HT + h];
+        }
+        bool dense_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) {
+                double* wfl = wt + HT * (P + 1);             // Wf (HS x D) behind the two-particle weights
+                for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
+                b.sync();
+                jac_factors_mfma(b, *wf, n, (double*)lds, o, wfl);
+                dense_done = true;
+            }
+        }
+#endif
         // per-particle left factors: item (i,a,g)
+        if (!dense_done)
         for (int e = b.tid; e < n * D * HS; e += b.nthr) {
             const int i = e / (D * HS), r = e - i * (D * HS), a = r / HS, g = r - a * HS;
             T ua = T(th[o_fw + g * D + a]), ub = T(0.0);
@@ -185,6 +387,7 @@ struct CgFast {
             }
             U[e] = ua; Bm[e] = ub;
         }
+        if (!dense_done)
         for (int e = b.tid; e < n * D * HT; e += b.nthr) {
             const int i = e / (D * HT), r = e - i * (D * HT), a = r / HT, g = r - a * HT;
             T v = T(0.0);
@@ -192,6 +395,9 @@ struct CgFast {
             for (int h = 0; h < HS; ++h) v += (th[o_fw + h * D + a] * th[o_Wc + g * HS + h]) * sg2[i * HS + h];
             V[e] = v * rn;
         }
+#if defined(CG_JAC_STOP)
+        if (CG_JAC_STOP == 1) { b.sync(); return; }
+#endif
         // G pass: item (k,h)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;
@@ -203,6 +409,7 @@ struct CgFast {
             T acc[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) acc[a] = T(0.0);
+#pragma unroll 2
             for (int l = 0; l < n; ++l) {
                 if (l == k) continue;
                 PairFT<T> pf; pairfeat(sh, ch, k, l, pf);
@@ -220,6 +427,15 @@ struct CgFast {
             for (int bb = 0; bb < D; ++bb) G[(k * HS + h) * D + bb] = acc[bb] * rn * rn;
         }
         b.sync();
+#if defined(CG_JAC_STOP)
+        if (CG_JAC_STOP == 2) return;
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) jac_up_mfma(b, *wf, n, (double*)lds, o);
+        }
+#endif
+        if (!dense_done)
         for (int e = b.tid; e < n * D * P; e += b.nthr) {      // U'_i: item (i,a,f)
             const int i = e / (D * P), r = e - i * (D * P), a = r / P, f = r - a * P;
             T v = T(0.0);
@@ -228,6 +444,9 @@ struct CgFast {
             Up[e] = v * rn;
         }
         b.sync();
+#if defined(CG_JAC_STOP)
+        if (CG_JAC_STOP == 3) return;
+#endif
         // Jacobian pass: item (i,k), k != i
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, k = e - i * n;
@@ -246,13 +465,15 @@ struct CgFast {
                                   Up[(i * D + a) * P + 2 * D] * td[bb]);
 #pragma unroll 4
             for (int h = 0; h < HT; ++h) {
-                T u = th[o_t0b + h] + th[o_t0w + 2 * D * HT + h] * pf.del;
+                const double* wh = wt + h * (P + 1);
+                const double wd = wh[1 + 2 * D];
+                T u = wh[0] + wd * pf.del;
                 T q[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const double wc = th[o_t0w + a * HT + h], ws = th[o_t0w + (D + a) * HT + h];
+                    const double wc = wh[1 + a], ws = wh[1 + D + a];
                     u += wc * pf.c2[a] + ws * pf.s2[a];
-                    q[a] = wc * tc[a] + ws * ts[a] + th[o_t0w + 2 * D * HT + h] * td[a];
+                    q[a] = wc * tc[a] + ws * ts[a] + wd * td[a];
                 }
                 const T sg = cg_sigmoid(u);
 #pragma unroll
@@ -310,9 +531,10 @@ struct CgFast {
     // also returns the two pieces separately (make_logphi_logjacdet, src/logpsi.py:35-53).
     static CG_DEVI void logpsi(const CgBlk& b, const double* __restrict__ th, const double* x /*LDS*/,
                                const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                               double* lds, const CgFastLds& o, double& re_phi, double& im_phi, double& half_logdetJ) {
-        primal(b, th, x, n, L, lds, o);
-        jacobian(b, th, n, L, lds, o);
+                               double* lds, const CgFastLds& o, double& re_phi, double& im_phi, double& half_logdetJ,
+                               const WFrag* wf = nullptr) {
+        primal(b, th, x, n, L, lds, o, wf);
+        jacobian(b, th, n, L, lds, o, wf);
         int* perm = (int*)(lds + o.perm);
         double la, ar;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -323,12 +545,14 @@ struct CgFast {
             double* res = (double*)perm;
             const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
             if (wave == 0) {
-                const double v = cg_wave_lu_logabsdet<32>(lds + o.J, n * D, n * D);
+                const int NN = n * D;
+                const double v = NN == 26 ? cg_wave_lu_logabsdet<26>(lds + o.J, NN, NN) : cg_wave_lu_logabsdet<32>(lds + o.J, NN, NN);
                 if (b.tid == 0) res[0] = v;
             }
             if (wave == cw) {
                 double l2, a2;
-                cg_wave_lu_logdet_complex<16>(lds + o.Dm, n, n, l2, a2);
+                if (n == 13) cg_wave_lu_logdet_complex<13>(lds + o.Dm, n, n, l2, a2);
+                else cg_wave_lu_logdet_complex<16>(lds + o.Dm, n, n, l2, a2);
                 if ((b.tid & 63) == 0) { res[1] = l2; res[2] = a2; }
             }
             b.sync();
@@ -360,6 +584,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
     o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
     o.sg1 = take(n * HS); o.sg2 = take(n * HS);
     o.perm = take((n * D + 1) / 2 + 1);
+    o.wt = take(HT * (P + 1) + HS * D);                 // two-particle layer weights [h][bias, P weights], then Wf (HS x D)
     if (!alias) {
         o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
         o.U = take(n * D * HS); o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P); o.G = take(n * HS * D);

@@ -45,12 +45,16 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_l
     __syncthreads();
     const int n = m.n, N = n * D;
     double* xs = lds + m.lay.total;
+    typename F::WFrag wfrag; const typename F::WFrag* wf = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (HS == 16 && HT == 16) { F::load_frags(theta, wfrag); wf = &wfrag; }
+#endif
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
         for (int e = b.tid; e < N; e += b.nthr) xs[e] = x[(size_t)w * N + e];
         b.sync();
         if (mode == CG_MODE_LOGPSI) {
             double re, im, h;
-            F::logpsi(b, theta, xs, spk, sidx + (size_t)w * n, n, m.L, lds, m.lay, re, im, h);
+            F::logpsi(b, theta, xs, spk, sidx + (size_t)w * n, n, m.L, lds, m.lay, re, im, h, wf);
             if (b.tid == 0) {
                 if (logphi) { logphi[2 * w] = re; logphi[2 * w + 1] = im; }
                 if (hld) hld[w] = h;
@@ -58,11 +62,11 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_l
                 if (logp_out) logp_out[w] = 2.0 * (re + h);
             }
         } else {
-            F::primal(b, theta, xs, n, m.L, lds, m.lay);
+            F::primal(b, theta, xs, n, m.L, lds, m.lay, wf);
             if (z_out)
                 for (int e = b.tid; e < N; e += b.nthr) z_out[(size_t)w * N + e] = lds[m.lay.z + e];
             if (mode == CG_MODE_JAC) {
-                F::jacobian(b, theta, n, m.L, lds, m.lay);
+                F::jacobian(b, theta, n, m.L, lds, m.lay, wf);
                 for (int e = b.tid; e < N * N; e += b.nthr) J_out[(size_t)w * N * N + e] = lds[m.lay.J + e];
             }
         }
@@ -86,33 +90,44 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
     double* xc = lds + m.lay.total;          // current configuration
     double* xp = xc + ((N + 1) & ~1);        // proposal
     int* flag = (int*)(xp + ((N + 1) & ~1));
+    typename F::WFrag wfrag; const typename F::WFrag* wf = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (HS == 16 && HT == 16) { F::load_frags(theta, wfrag); wf = &wfrag; }
+#endif
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
         const int* si = sidx + (size_t)w * n;
         for (int e = b.tid; e < N; e += b.nthr) xc[e] = x[(size_t)w * N + e];
         b.sync();
-        double re, im, h;
-        F::logpsi(b, theta, xc, spk, si, n, m.L, lds, m.lay, re, im, h);
-        double logp = 2.0 * (re + h);
+        double logp = 0.0;
         unsigned int nacc = 0;
-        for (int s = 0; s < steps; ++s) {
+        // step -1 evaluates logp of the initial configuration (src/MCMC.py:36) through the SAME call site as the
+        // proposals, so that the (large, unrolled) log Psi code exists once in the instruction stream.
+        for (int s = -1; s < steps; ++s) {
             for (int e = b.tid; e < N; e += b.nthr) {
-                const double g = noise ? noise[((size_t)s * B + w) * N + e]
-                                       : cg_philox_normal(seed, walker_offset + w, (uint32_t)s, (uint32_t)e);
+                double g = 0.0;
+                if (s >= 0) g = noise ? noise[((size_t)s * B + w) * N + e]
+                                      : cg_philox_normal(seed, walker_offset + w, (uint32_t)s, (uint32_t)e);
                 xp[e] = xc[e] + stddev * g;
             }
             b.sync();
-            F::logpsi(b, theta, xp, spk, si, n, m.L, lds, m.lay, re, im, h);
+            double re, im, h;
+            F::logpsi(b, theta, xp, spk, si, n, m.L, lds, m.lay, re, im, h, wf);
             const double lp = 2.0 * (re + h);
             if (b.tid == 0) {
-                const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
-                const double ratio = exp(lp - logp);
-                *flag = (u < ratio) ? 1 : 0;          // NaN -> reject, +inf -> accept (src/MCMC.py:28-29)
+                int acc = 1;
+                if (s >= 0) {
+                    const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
+                    const double ratio = exp(lp - logp);
+                    acc = (u < ratio) ? 1 : 0;            // NaN -> reject, +inf -> accept (src/MCMC.py:28-29)
+                }
+                *flag = acc;
             }
             b.sync();
             const int acc = *flag;
             if (acc) {
                 for (int e = b.tid; e < N; e += b.nthr) xc[e] = xp[e];
-                logp = lp; ++nacc;
+                logp = lp;
+                if (s >= 0) ++nacc;
             }
             b.sync();
         }
