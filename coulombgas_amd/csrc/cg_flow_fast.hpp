@@ -93,6 +93,8 @@ struct CgFast {
         double bf;         // final bias by column (0 beyond D)
         double ja[4], jb[4], jc[4];   // Wa^T, Wb^T, Wc^T (k = h, col = g): R_i W_x^T
         double w0t[4];     // W0^T (k = g, col = f < P)
+        double tw[P + 1];  // two-particle layer column h = lane & 15: bias, then P weights  (pair-primal pass)
+        double gw[P];      // W0 column h = lane & 15                                        (G pass)
     };
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -117,6 +119,121 @@ struct CgFast {
             w.w0t[ks] = col < P ? th[o_W0 + col * HS + k] : 0.0;   // B[k = g][col = f] = W0[f][g]
         }
         w.bf = col < D ? th[o_fb + col] : 0.0;
+        w.tw[0] = th[o_t0b + col];
+#pragma unroll
+        for (int f = 0; f < P; ++f) { w.tw[1 + f] = th[o_t0w + f * HT + col]; w.gw[f] = th[o_W0 + f * HS + col]; }
+    }
+    // broadcast lane LANE of every 16-lane DPP row to the whole row (row_newbcast, gfx90a+)
+    template <int LANE>
+    static __device__ __forceinline__ double row_bcast(double v) {
+        const long long u = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)u, 0x150 + LANE, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x150 + LANE, 0xf, 0xf, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    }
+    struct PF6 { double c2[D], s2[D], del, rdel; };
+    template <int LANE>
+    static __device__ __forceinline__ void pf_bcast(const PF6& mine, PF6& out) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) { out.c2[a] = row_bcast<LANE>(mine.c2[a]); out.s2[a] = row_bcast<LANE>(mine.s2[a]); }
+        out.del = row_bcast<LANE>(mine.del); out.rdel = row_bcast<LANE>(mine.rdel);
+    }
+    // Pair-primal pass with shared pair features: a DPP row (16 lanes) owns particle i, lane h = hidden unit.
+    // Each lane computes the features of ONE pair (i, j = 16 c + h); the row then walks j = 16 c + jj and every
+    // lane receives pair (i, j) by row broadcast -- 12 v_mov_dpp instead of recomputing ~45 instructions.
+    template <int JJ>
+    static __device__ __forceinline__ void primal_pair_step(const PF6& mine, const WFrag& w, int i, int jbase, int n, int h,
+                                                            double& acc, double& raw) {
+        if constexpr (JJ < 16) {
+            if (jbase + JJ < n) {                                  // wave-uniform
+                PF6 pf; pf_bcast<JJ>(mine, pf);
+                if (i == jbase + JJ) {                             // exact diagonal feature (src/flow.py:25)
+#pragma unroll
+                    for (int a = 0; a < D; ++a) { pf.c2[a] = 1.0; pf.s2[a] = 0.0; }
+                    pf.del = 0.0;
+                }
+                double u = w.tw[0] + w.tw[1 + 2 * D] * pf.del;
+#pragma unroll
+                for (int a = 0; a < D; ++a) u += w.tw[1 + a] * pf.c2[a] + w.tw[1 + D + a] * pf.s2[a];
+                acc += softplus_only(u);
+                double fv = pf.del;
+#pragma unroll
+                for (int a = 0; a < D; ++a) { if (h == a) fv = pf.c2[a]; if (h == D + a) fv = pf.s2[a]; }
+                raw += fv;
+                primal_pair_step<JJ + 1>(mine, w, i, jbase, n, h, acc, raw);
+            }
+        }
+    }
+    static __device__ __forceinline__ void own_pair(const double* sh, const double* ch, int i, int j, bool ok, PF6& f) {
+        double d2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const double si = ok ? sh[i * D + a] : 0.0, ci = ok ? ch[i * D + a] : 1.0, sj = ok ? sh[j * D + a] : 1.0, cj = ok ? ch[j * D + a] : 0.0;
+            const double s = si * cj - ci * sj, c = ci * cj + si * sj;
+            f.s2[a] = 2.0 * (s * c); f.c2[a] = 1.0 - 2.0 * (s * s); d2 += s * s;
+        }
+        f.del = sqrt(d2);
+        f.rdel = (ok && i != j) ? 1.0 / f.del : 0.0;
+    }
+    static __device__ __forceinline__ void primal_pairs_dpp(const CgBlk& b, const WFrag& w, int n, double* lds, const CgFastLds& o) {
+        const double *sh = lds + o.sh, *ch = lds + o.ch;
+        double *m0 = lds + o.m0, *m1 = lds + o.m1;
+        const double rn = 1.0 / (double)n;
+        const int h = b.tid & 15;
+        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {      // whole waves stay together
+            const int i = (e0 + (b.tid & 63)) >> 4;
+            const bool rowok = i < n;
+            double acc = 0.0, raw = 0.0;
+            for (int jb = 0; jb < n; jb += 16) {
+                PF6 mine; own_pair(sh, ch, rowok ? i : 0, jb + h, rowok && jb + h < n, mine);
+                primal_pair_step<0>(mine, w, i, jb, n, h, acc, raw);
+            }
+            if (rowok) { m1[i * HT + h] = acc * rn; if (h < P) m0[i * P + h] = raw * rn; }
+        }
+    }
+    // G pass with shared pair features (same row layout: row = particle k, lane = hidden unit h)
+    template <int LL>
+    static __device__ __forceinline__ void g_pair_step(const PF6& mine, const WFrag& w, int k, int lbase, int n, int h,
+                                                       double sgk, const double* sg1, double c1, double c2c, double* acc) {
+        if constexpr (LL < 16) {
+            if (lbase + LL < n) {
+                PF6 pf; pf_bcast<LL>(mine, pf);
+                const int l = lbase + LL;
+                const double sgl = sg1[l * HS + h];
+                if (l != k) {
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) {
+                        const double odd = (-c1 * w.gw[bb]) * pf.s2[bb] + (c2c * w.gw[2 * D]) * (pf.s2[bb] * pf.rdel);
+                        const double evn = (c1 * w.gw[D + bb]) * pf.c2[bb];
+                        acc[bb] += sgk * (odd + evn) - sgl * (evn - odd);
+                    }
+                }
+                g_pair_step<LL + 1>(mine, w, k, lbase, n, h, sgk, sg1, c1, c2c, acc);
+            }
+        }
+    }
+    static __device__ __forceinline__ void g_pass_dpp(const CgBlk& b, const WFrag& w, int n, double L, double* lds, const CgFastLds& o) {
+        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1;
+        double* G = lds + o.G;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        const int h = b.tid & 15;
+        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {
+            const int k = (e0 + (b.tid & 63)) >> 4;
+            const bool rowok = k < n;
+            const double sgk = rowok ? sg1[k * HS + h] : 0.0;
+            double acc[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) acc[a] = 0.0;
+            for (int lb = 0; lb < n; lb += 16) {
+                PF6 mine; own_pair(sh, ch, rowok ? k : 0, lb + h, rowok && lb + h < n, mine);
+                g_pair_step<0>(mine, w, k, lb, n, h, sgk, sg1, c1, c2c, acc);
+            }
+            if (rowok) {
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) G[(k * HS + h) * D + bb] = acc[bb] * rn * rn;
+            }
+        }
     }
     // dense part of primal(): needs m0, m1 in LDS; fills s1 sg1 sg2 s2 z.  Executed by wave 0; others wait.
     static __device__ __forceinline__ void primal_dense_mfma(const CgBlk& b, const WFrag& w, const double* x, int n,
@@ -266,8 +383,15 @@ struct CgFast {
             sh[e] = s; ch[e] = c;
         }
         b.sync();
+        bool pairs_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) { primal_pairs_dpp(b, *wf, n, (double*)lds, o); pairs_done = true; }
+        }
+#endif
         // pair-primal: item (i,h)
         constexpr int HM = HT > P ? HT : P;          // lanes h < P also carry one raw-feature mean
+        if (!pairs_done)
         for (int e = b.tid; e < n * HM; e += b.nthr) {
             const int i = e / HM, h = e - i * HM;
             double wt[P], bt = 0.0;
@@ -399,6 +523,12 @@ struct CgFast {
         if (CG_JAC_STOP == 1) { b.sync(); return; }
 #endif
         // G pass: item (k,h)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) g_pass_dpp(b, *wf, n, L, (double*)lds, o);
+        }
+#endif
+        if (!dense_done)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;
             double w_c[D], w_s[D];
