@@ -276,7 +276,7 @@ struct CgDerivs {
             double acc = 0;
             for (int k = 0; k < n; ++k)
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[(k * HS + g) * D + bb];
+                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[F::iG(k, g, bb)];
             Bb[e] = acc;
         }
         for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
@@ -284,7 +284,7 @@ struct CgDerivs {
             double acc = 0;
             for (int i = 0; i < n; ++i)
 #pragma unroll
-                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[(i * D + a) * HS + g];
+                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[F::iB(i, a, g)];
             Gb[e] = acc;
         }
         // (J5) pair pass in (i,h) layout: Vbar_i[:,h], and the sigma_t / q_t adjoints -> partial Wtbar / btbar
@@ -314,7 +314,7 @@ struct CgDerivs {
                 for (int bb = 0; bb < D; ++bb) qb[bb] = 0;
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const double vih = V[(i * D + a) * HT + h];
+                    const double vih = V[F::iV(i, a, h)];
 #pragma unroll
                     for (int bb = 0; bb < D; ++bb) {
                         const double jh = Jhat[(i * D + a) * N + k * D + bb];

@@ -51,6 +51,13 @@ struct CgFast {
     static constexpr int o_Wb = o_s1w + HS * HS;
     static constexpr int o_Wc = o_s1w + 2 * HS * HS;
 
+    // per-particle strides of V, Bm, G padded by 2 doubles: the Jacobian pass reads them with the particle index
+    // varying across lanes, and an unpadded 32-double stride maps every particle to the same LDS banks
+    static constexpr int SPV = HT * D + 2, SPB = HS * D + 2, SPG = HS * D + 2;
+    static CG_HD int iV(int i, int a, int h) { return i * SPV + h * D + a; }
+    static CG_HD int iB(int i, int a, int g) { return i * SPB + g * D + a; }
+    static CG_HD int iG(int k, int g, int bb) { return k * SPG + g * D + bb; }
+
     template <class T> struct PairFT { T s2[D], c2[D], del; };
     using PairF = PairFT<double>;
 
@@ -231,7 +238,7 @@ struct CgFast {
             }
             if (rowok) {
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) G[(k * HS + h) * D + bb] = acc[bb] * rn * rn;
+                for (int bb = 0; bb < D; ++bb) G[iG(k, h, bb)] = acc[bb] * rn * rn;
             }
         }
     }
@@ -338,7 +345,7 @@ struct CgFast {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = 16 * t + kq + 4 * r;
-                if (rr < N) { U[rr * HS + col] = cu[r]; Bm[rr * HS + col] = cbm[r]; V[rr * HT + col] = cv[r] * rn; }
+                if (rr < N) { const int ii = rr / D, ar = rr - ii * D; U[rr * HS + col] = cu[r]; Bm[iB(ii, ar, col)] = cbm[r]; V[iV(ii, ar, col)] = cv[r] * rn; }
             }
         }
     }
@@ -509,7 +516,7 @@ struct CgFast {
                 ua += rih * th[o_Wa + g * HS + h];
                 ub += rih * th[o_Wb + g * HS + h];
             }
-            U[e] = ua; Bm[e] = ub;
+            U[e] = ua; Bm[iB(i, a, g)] = ub;
         }
         if (!dense_done)
         for (int e = b.tid; e < n * D * HT; e += b.nthr) {
@@ -517,7 +524,7 @@ struct CgFast {
             T v = T(0.0);
 #pragma unroll
             for (int h = 0; h < HS; ++h) v += (th[o_fw + h * D + a] * th[o_Wc + g * HS + h]) * sg2[i * HS + h];
-            V[e] = v * rn;
+            V[iV(i, a, g)] = v * rn;
         }
 #if defined(CG_JAC_STOP)
         if (CG_JAC_STOP == 1) { b.sync(); return; }
@@ -554,7 +561,7 @@ struct CgFast {
                 }
             }
 #pragma unroll
-            for (int bb = 0; bb < D; ++bb) G[(k * HS + h) * D + bb] = acc[bb] * rn * rn;
+            for (int bb = 0; bb < D; ++bb) G[iG(k, h, bb)] = acc[bb] * rn * rn;
         }
         b.sync();
 #if defined(CG_JAC_STOP)
@@ -608,7 +615,7 @@ struct CgFast {
                 const T sg = cg_sigmoid(u);
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const T vs = V[(i * D + a) * HT + h] * sg;
+                    const T vs = V[iV(i, a, h)] * sg;
 #pragma unroll
                     for (int bb = 0; bb < D; ++bb) Jb[a][bb] -= vs * q[bb];
                 }
@@ -617,9 +624,9 @@ struct CgFast {
             for (int g = 0; g < HS; ++g) {
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const T bg = Bm[(i * D + a) * HS + g];
+                    const T bg = Bm[iB(i, a, g)];
 #pragma unroll
-                    for (int bb = 0; bb < D; ++bb) Jb[a][bb] += bg * G[(k * HS + g) * D + bb];
+                    for (int bb = 0; bb < D; ++bb) Jb[a][bb] += bg * G[iG(k, g, bb)];
                 }
             }
 #pragma unroll
@@ -717,7 +724,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
     o.wt = take(HT * (P + 1) + HS * D);                 // two-particle layer weights [h][bias, P weights], then Wf (HS x D)
     if (!alias) {
         o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
-        o.U = take(n * D * HS); o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P); o.G = take(n * HS * D);
+        o.U = take(n * D * HS); o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
         o.J = take(n * D * n * D);
         o.Dm = take(2 * n * n);
         o.total = t;
@@ -728,7 +735,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
     o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
     const int end_primal = t;
     t = base;
-    o.V = take(n * D * HT); o.Bm = take(n * D * HS); o.Up = take(n * D * P); o.G = take(n * HS * D);
+    o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
     const int end_jac = t;
     t = end_primal > end_jac ? end_primal : end_jac;
     o.J = take(n * D * n * D);
