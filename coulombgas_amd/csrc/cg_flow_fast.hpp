@@ -317,7 +317,8 @@ struct CgFast {
         }
         b.sync();
     }
-    // U, Bm, V of jacobian(): rows r = (i,a).  wfl: Wf (HS x D) staged in LDS.
+    // U, Bm (which = 0) or V (which = 1) of jacobian(): rows r = (i,a).  wfl: Wf (HS x D) staged in LDS.
+    template <int WHICH>
     static __device__ __forceinline__ void jac_factors_mfma(const CgBlk& b, const WFrag& w, int n, double* lds,
                                                             const CgFastLds& o, const double* wfl) {
         const double* sg2 = lds + o.sg2;
@@ -328,24 +329,55 @@ struct CgFast {
         const double rn = 1.0 / (double)n;
         for (int t = wave; t < tiles; t += nw) {
             const int ra = 16 * t + col, ia = ra / D, aa = ra - ia * D;
-            d4_t cu, cbm = {0, 0, 0, 0}, cv = {0, 0, 0, 0};
+            d4_t cu = {0, 0, 0, 0}, cbm = {0, 0, 0, 0};
+            if (WHICH == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * t + kq + 4 * r;
-                cu[r] = rr < N ? wfl[col * D + (rr % D)] : 0.0;      // direct term Wf[g][a]
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = 16 * t + kq + 4 * r;
+                    cu[r] = rr < N ? wfl[col * D + (rr % D)] : 0.0;      // direct term Wf[g][a]
+                }
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int h = 4 * ks + kq;
                 const double a = ra < N ? wfl[h * D + aa] * sg2[ia * HS + h] : 0.0;   // R_i[a][h]
-                cu = mfma(a, w.ja[ks], cu);
-                cbm = mfma(a, w.jb[ks], cbm);
-                cv = mfma(a, w.jc[ks], cv);
+                if (WHICH == 0) { cu = mfma(a, w.ja[ks], cu); cbm = mfma(a, w.jb[ks], cbm); }
+                else cu = mfma(a, w.jc[ks], cu);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = 16 * t + kq + 4 * r;
-                if (rr < N) { const int ii = rr / D, ar = rr - ii * D; U[rr * HS + col] = cu[r]; Bm[iB(ii, ar, col)] = cbm[r]; V[iV(ii, ar, col)] = cv[r] * rn; }
+                if (rr < N) {
+                    const int ii = rr / D, ar = rr - ii * D;
+                    if (WHICH == 0) { U[rr * HS + col] = cu[r]; Bm[iB(ii, ar, col)] = cbm[r]; }
+                    else V[iV(ii, ar, col)] = cu[r] * rn;
+                }
+            }
+        }
+    }
+    // J[r][c] = sum_g Bm[r][g] G[g][c]  (r = (i,a), c = (k,b)): the rank-16 term B_i G_k of every block at once
+    static __device__ __forceinline__ void jac_bg_mfma(const CgBlk& b, int n, double* lds, const CgFastLds& o) {
+        const double *Bm = lds + o.Bm, *G = lds + o.G;
+        double* J = lds + o.J;
+        const int l = b.tid & 63, col = l & 15, kq = l >> 4;
+        const int wave = b.tid >> 6, nw = b.nthr >> 6;
+        const int N = n * D, tiles = (N + 15) >> 4;
+        for (int tt = wave; tt < tiles * tiles; tt += nw) {
+            const int t = tt / tiles, u = tt - t * tiles;
+            const int ra = 16 * t + col, ia = ra / D, aa = ra - ia * D;       // A row
+            const int cb = 16 * u + col, kb = cb / D, bb = cb - kb * D;       // B column
+            d4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int g = 4 * ks + kq;
+                const double av = ra < N ? Bm[iB(ia, aa, g)] : 0.0;
+                const double bv = cb < N ? G[iG(kb, g, bb)] : 0.0;
+                c = mfma(av, bv, c);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + kq + 4 * r;
+                if (rr < N && cb < N) J[rr * N + cb] = c[r];
             }
         }
     }
@@ -372,6 +404,81 @@ struct CgFast {
                 if (rr < N && col < P) Up[rr * P + col] = c[r] * rn;
             }
         }
+    }
+    // The whole Jacobian assembly on the MFMA / DPP path (double, spsize = tpsize = 16).  Order chosen so that
+    // V can reuse Bm's LDS slot:  U,Bm | G  ->  Up  ->  J = Bm G  ->  V  ->  J += pair part  ->  diagonal blocks.
+    static __device__ __forceinline__ void jacobian_mfma(const CgBlk& b, const double* __restrict__ th, const WFrag& w, int n,
+                                                         double L, double* lds, const CgFastLds& o) {
+        const double *sh = lds + o.sh, *ch = lds + o.ch;
+        double *V = lds + o.V, *Up = lds + o.Up, *J = lds + o.J;
+        const int N = n * D;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        double* wt = lds + o.wt;
+        double* wfl = wt + HT * (P + 1);
+        for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
+            const int h = e / (P + 1), f = e - h * (P + 1);
+            wt[e] = f == 0 ? th[o_t0b + h] : th[o_t0w + (f - 1) * HT + h];
+        }
+        for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
+        b.sync();
+        jac_factors_mfma<0>(b, w, n, lds, o, wfl);
+        g_pass_dpp(b, w, n, L, lds, o);
+        b.sync();
+        jac_up_mfma(b, w, n, lds, o);
+        b.sync();
+        jac_bg_mfma(b, n, lds, o);
+        b.sync();
+        jac_factors_mfma<1>(b, w, n, lds, o, wfl);
+        b.sync();
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = e / n, k = e - i * n;
+            if (i == k) continue;
+            PairF pf; pairfeat(sh, ch, i, k, pf);
+            const double rdel = 1.0 / pf.del;
+            double tc[D], ts[D], td[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * (pf.s2[bb] * rdel); }
+            double Jb[D][D];
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb)
+                    Jb[a][bb] = J[(i * D + a) * N + k * D + bb]
+                                - (Up[(i * D + a) * P + bb] * tc[bb] + Up[(i * D + a) * P + D + bb] * ts[bb] + Up[(i * D + a) * P + 2 * D] * td[bb]);
+#pragma unroll 4
+            for (int h = 0; h < HT; ++h) {
+                const double* wh = wt + h * (P + 1);
+                const double wd = wh[1 + 2 * D];
+                double u = wh[0] + wd * pf.del;
+                double q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double wc = wh[1 + a], ws = wh[1 + D + a];
+                    u += wc * pf.c2[a] + ws * pf.s2[a];
+                    q[a] = wc * tc[a] + ws * ts[a] + wd * td[a];
+                }
+                const double sg = sigmoid_only(u);
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double vs = V[iV(i, a, h)] * sg;
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) Jb[a][bb] -= vs * q[bb];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) J[(i * D + a) * N + k * D + bb] = Jb[a][bb];
+        }
+        b.sync();
+        for (int e = b.tid; e < n * D * D; e += b.nthr) {
+            const int i = e / (D * D), r = e - i * (D * D), a = r / D, bb = r - a * D;
+            double v = (a == bb) ? 1.0 : 0.0;
+            for (int k = 0; k < n; ++k)
+                if (k != i) v -= J[(i * D + a) * N + k * D + bb];
+            J[(i * D + a) * N + i * D + bb] = v;
+        }
+        b.sync();
     }
 #endif
 
@@ -487,26 +594,18 @@ struct CgFast {
         const int N = n * D;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+            if (wf) { jacobian_mfma(b, th, *wf, n, L, (double*)lds, o); return; }
+        }
+#endif
         // two-particle layer weights -> arena, [h][bias, w_0..w_{P-1}]: the Jacobian pass reads them with broadcast loads
         double* wt = (double*)(lds + o.wt);
         for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
             const int h = e / (P + 1), f = e - h * (P + 1);
             wt[e] = f == 0 ? th[o_t0b + h] : th[o_t0w + (f - 1) * HT + h];
         }
-        bool dense_done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
-            if (wf) {
-                double* wfl = wt + HT * (P + 1);             // Wf (HS x D) behind the two-particle weights
-                for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
-                b.sync();
-                jac_factors_mfma(b, *wf, n, (double*)lds, o, wfl);
-                dense_done = true;
-            }
-        }
-#endif
         // per-particle left factors: item (i,a,g)
-        if (!dense_done)
         for (int e = b.tid; e < n * D * HS; e += b.nthr) {
             const int i = e / (D * HS), r = e - i * (D * HS), a = r / HS, g = r - a * HS;
             T ua = T(th[o_fw + g * D + a]), ub = T(0.0);
@@ -518,7 +617,6 @@ struct CgFast {
             }
             U[e] = ua; Bm[iB(i, a, g)] = ub;
         }
-        if (!dense_done)
         for (int e = b.tid; e < n * D * HT; e += b.nthr) {
             const int i = e / (D * HT), r = e - i * (D * HT), a = r / HT, g = r - a * HT;
             T v = T(0.0);
@@ -530,12 +628,6 @@ struct CgFast {
         if (CG_JAC_STOP == 1) { b.sync(); return; }
 #endif
         // G pass: item (k,h)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
-            if (wf) g_pass_dpp(b, *wf, n, L, (double*)lds, o);
-        }
-#endif
-        if (!dense_done)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;
             double w_c[D], w_s[D];
@@ -567,12 +659,6 @@ struct CgFast {
 #if defined(CG_JAC_STOP)
         if (CG_JAC_STOP == 2) return;
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
-            if (wf) jac_up_mfma(b, *wf, n, (double*)lds, o);
-        }
-#endif
-        if (!dense_done)
         for (int e = b.tid; e < n * D * P; e += b.nthr) {      // U'_i: item (i,a,f)
             const int i = e / (D * P), r = e - i * (D * P), a = r / P, f = r - a * P;
             T v = T(0.0);
@@ -715,7 +801,7 @@ struct CgFast {
 //       jacobian        U (dead once Up is formed)                                    -> lives inside J
 //                       V Bm Up G J
 //       Slater matrix   Dm: after the LU of J                                          -> on top of V Bm Up G, or on J
-static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias) {
+static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, bool mfma = false) {
     CgFastLds o; int P = 2 * D + 1, t = 0;
     auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
     o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
@@ -735,7 +821,10 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias)
     o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
     const int end_primal = t;
     t = base;
-    o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
+    // MFMA path (device, spsize = tpsize = 16): V is formed after the B.G product and reuses Bm's slot
+    if (mfma && HS == HT) { o.Bm = take(n * (HS * D + 2)); o.V = o.Bm; }
+    else { o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); }
+    o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
     const int end_jac = t;
     t = end_primal > end_jac ? end_primal : end_jac;
     o.J = take(n * D * n * D);

@@ -392,7 +392,7 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
 #define CG_X(D, HS, HT) if (dim == D && spsize == HS && tpsize == HT) c->P = CgFast<D, HS, HT>::NPARAM;
     CG_FAST_CONFIGS(CG_X)
 #undef CG_X
-    c->lay = cg_fast_layout(n, dim, spsize, tpsize, true);
+    c->lay = cg_fast_layout(n, dim, spsize, tpsize, true, spsize == 16 && tpsize == 16);
     auto fail = [&](const char* what, hipError_t err) {
         g_last_error = std::string("cg_create: ") + what + ": " + hipGetErrorString(err);
         delete c; return CG_ERR_HIP;
