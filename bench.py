@@ -93,7 +93,8 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
             sys.exit(2)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("CG_FORCE_DIST") == "1"        # exercise the N > 1 code path on a 1-GPU box
+    if world > 1 or force_dist:
         import torch, torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -108,7 +109,7 @@ def main():
     eng.set_params(theta)
     if args.threads:
         eng.set_block_threads(args.threads)
-    comm = RcclComm(eng, rank, world) if world > 1 else NullComm()
+    comm = RcclComm(eng, rank, world) if (world > 1 or force_dist) else NullComm()
 
     eng.device_mode(True)
     d_x = eng.alloc((B, n, dim)).upload(x)
@@ -125,7 +126,7 @@ def main():
     def sampling_call(it):
         eng.mcmc_dev(d_x, d_s, B, args.mc_steps, args.mc_stddev, seed=42 + it, walker_offset=rank * B, logp_buf=d_lp)
         eng.wrap_dev(d_x, B)                                   # src/VMC.py:24
-        if world > 1:                                          # src/MCMC.py:39 pmean of the accept rate
+        if world > 1 or force_dist:                            # src/MCMC.py:39 pmean of the accept rate
             rate = eng.mcmc_accepts() / float(args.mc_steps * B)
             return comm.pmean(rate)
         return None
@@ -140,7 +141,7 @@ def main():
         eng.mcmc_dev(d_x, d_s, B, args.mc_steps, args.mc_stddev, seed=4242 + it, walker_offset=rank * B, logp_buf=d_lp)
         kernel_ms += eng.timer_stop()                          # HIP events on the kernel's own stream
         eng.wrap_dev(d_x, B)
-        if world > 1:
+        if world > 1 or force_dist:
             comm.pmean(eng.mcmc_accepts() / float(args.mc_steps * B))
     barrier()
     elapsed = time.perf_counter() - t0

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.common import orbitals, box_length, flow_theta, state_indices, walkers
+from tests.common import orbitals, box_length, flow_theta, state_indices, walkers, GOLDEN as GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
 
@@ -292,3 +292,40 @@ def test_rccl_allreduce_world1():
     assert np.array_equal(comm.pmean(a), a)
     assert comm.pmean(3.5) == 3.5
     comm.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# largest published sizes (BASELINE configs 4 and 5): checked against the C oracle (dense forward mode, AD-free),
+# the torch.func oracle being too slow there
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,Emax,B", [(29, 25, 6), (57, 49, 3)])
+def test_large_n_against_c_oracle(n, Emax, B):
+    import ctypes as C
+    import coulombgas_amd as cg
+    from coulombgas_amd.build import build_oracle
+    lib = C.CDLL(build_oracle())
+    lib.cgo_mcmc.restype = C.c_double
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    dim, L = 2, box_length(n, 2)
+    rng = np.random.default_rng(n)
+    sp = orbitals(2, Emax)
+    theta = np.load(GOLDEN_DIR + "/shipped_n%d_rs10.npz" % n)["theta"]          # trained flow of the shipped run
+    x = walkers(rng, B, n, dim, L)
+    sidx = state_indices(rng, B, n, sp.shape[0])
+    flow = cg.FermiNet(2, 16, 16, L)
+    eng = flow.engine(n, dim, sp)
+    eng.set_params(theta)
+    out = np.zeros((B, 3))
+    lib.cgo_logpsi(n, dim, 2, 16, 16, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, p(out))
+    lphi, hld = eng.logphi_logjacdet(x, sidx)
+    assert np.abs(lphi[:, 0] - out[:, 0]).max() < 1e-10 * np.abs(out[:, 0]).max()
+    assert np.abs(np.angle(np.exp(1j * (lphi[:, 1] - out[:, 1])))).max() < 1e-10
+    assert np.abs(hld - out[:, 2]).max() < 1e-11
+    steps = 3
+    noise = rng.standard_normal((steps, B, n, dim)); unif = rng.uniform(size=(steps, B))
+    xg, lpg, nacc = eng.mcmc(x, sidx, steps, 0.1, noise=noise, unif=unif)
+    xc = x.copy(); lpc = np.zeros(B)
+    rate = lib.cgo_mcmc(n, dim, 2, 16, 16, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(xc), B, steps, C.c_double(0.1),
+                        p(noise), p(unif), p(lpc))
+    assert nacc / (steps * B) == pytest.approx(rate, abs=1e-15)
+    assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
