@@ -17,6 +17,7 @@
 #include "cg_rng.hpp"
 #include "cg_ewald.hpp"
 #include "cg_derivs.hpp"
+#include "cg_generic.hpp"
 
 // ------------------------------------------------------------------------------------------
 // device-side model descriptor (passed by value to every kernel)
@@ -219,6 +220,104 @@ __global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
 }
 
 
+
+// ---- general-depth path (cg_generic.hpp): any FermiNet depth / widths; workspace in HBM --------------------------
+__global__ void __launch_bounds__(256) k_gen_logpsi(CgGenModel m, CgGenWs w, const double* __restrict__ theta,
+                                                    const double* __restrict__ spk, const double* __restrict__ tab,
+                                                    const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+                                                    double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
+                                                    double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out,
+                                                    double* __restrict__ wsall) {
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    double* ws = wsall + (size_t)blockIdx.x * w.total;
+    const int n = m.n, N = n * m.dim;
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        if (mode == CG_MODE_LOGPSI) {
+            double re, im, h;
+            CgGenK::logpsi(b, m, w, theta, spk, sidx + (size_t)q * n, x + (size_t)q * N, ws, re, im, h);
+            if (b.tid == 0) {
+                if (logphi) { logphi[2 * q] = re; logphi[2 * q + 1] = im; }
+                if (hld) hld[q] = h;
+                if (logpsi_out) { logpsi_out[2 * q] = re + h; logpsi_out[2 * q + 1] = im; }
+                if (logp_out) logp_out[q] = 2.0 * (re + h);
+            }
+        } else {
+            CgGen<double>::flow(b, m, theta, x + (size_t)q * N, ws + w.da, mode == CG_MODE_JAC);
+            if (z_out) for (int e = b.tid; e < N; e += b.nthr) z_out[(size_t)q * N + e] = ws[w.da + m.o_z + e];
+            if (mode == CG_MODE_JAC) for (int e = b.tid; e < N * N; e += b.nthr) J_out[(size_t)q * N * N + e] = ws[w.da + m.o_J + e];
+        }
+        b.sync();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const double* __restrict__ theta,
+                                                  const double* __restrict__ spk, const double* __restrict__ tab, double* __restrict__ x,
+                                                  const int* __restrict__ sidx, int B, int steps, double stddev, uint64_t seed,
+                                                  uint64_t walker_offset, const double* __restrict__ noise, const double* __restrict__ unif,
+                                                  double* __restrict__ logp_out, unsigned long long* __restrict__ n_accept,
+                                                  double* __restrict__ wsall) {
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    int* flag = (int*)(cg_dyn_lds + CG_TAB_DOUBLES);
+    double* ws = wsall + (size_t)blockIdx.x * w.total;
+    double *xc = ws + w.xc, *xp = ws + w.xp;
+    const int n = m.n, N = n * m.dim;
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        const int* si = sidx + (size_t)q * n;
+        for (int e = b.tid; e < N; e += b.nthr) xc[e] = x[(size_t)q * N + e];
+        b.sync();
+        double logp = 0.0;
+        unsigned int nacc = 0;
+        for (int s = -1; s < steps; ++s) {
+            for (int e = b.tid; e < N; e += b.nthr) {
+                double g = 0.0;
+                if (s >= 0) g = noise ? noise[((size_t)s * B + q) * N + e] : cg_philox_normal(seed, walker_offset + q, (uint32_t)s, (uint32_t)e);
+                xp[e] = xc[e] + stddev * g;
+            }
+            b.sync();
+            double re, im, h;
+            CgGenK::logpsi(b, m, w, theta, spk, si, xp, ws, re, im, h);
+            const double lp = 2.0 * (re + h);
+            if (b.tid == 0) {
+                int acc = 1;
+                if (s >= 0) {
+                    const double u = unif ? unif[(size_t)s * B + q] : cg_philox_uniform(seed, walker_offset + q, (uint32_t)s);
+                    acc = (u < exp(lp - logp)) ? 1 : 0;
+                }
+                *flag = acc;
+            }
+            b.sync();
+            const int acc = *flag;
+            if (acc) { for (int e = b.tid; e < N; e += b.nthr) xc[e] = xp[e]; logp = lp; if (s >= 0) ++nacc; }
+            b.sync();
+        }
+        for (int e = b.tid; e < N; e += b.nthr) x[(size_t)q * N + e] = xc[e];
+        if (b.tid == 0) { if (logp_out) logp_out[q] = logp; if (n_accept && nacc) atomicAdd(n_accept, (unsigned long long)nacc); }
+        b.sync();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gen_grad_lap(CgGenModel m, CgGenWs w, const double* __restrict__ theta,
+                                                      const double* __restrict__ spk, const double* __restrict__ tab,
+                                                      const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+                                                      const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
+                                                      double* __restrict__ wsall) {
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
+    double* ws = wsall + (size_t)blockIdx.x * w.total;
+    const int n = m.n, N = n * m.dim;
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        CgGenK::grad_laplacian(b, m, w, theta, spk, sidx + (size_t)q * n, x + (size_t)q * N, mode, v ? v + (size_t)q * N : nullptr,
+                               grad + (size_t)q * N * 2, lap + 2 * q, ws, lds);
+        b.sync();
+    }
+}
+
 // fp64 peak micro-benchmarks (roofline denominators for bench.py; /opt/skills/guides has no f64 row)
 __global__ void __launch_bounds__(256) k_peak_fma64(double* out, int iters, double a, double b) {
     double v[16];
@@ -274,6 +373,8 @@ struct cg_ctx {
     int block_threads = 0;
     int cu_count = 256;
     CgFastLds lay;
+    CgGenModel gm;               // general-depth path (fast == false)
+    CgGenWs gw;
     unsigned long long* d_accept = nullptr;
     // staging arena for host-pointer mode + internal workspaces
     std::vector<Chunk> chunks;
@@ -379,20 +480,27 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
     if (n < 1 || (dim != 2 && dim != 3) || depth < 2 || spsize < 1 || tpsize < 1 || !(L > 0) || !sp_indices || M < n)
         CG_FAIL((cg_ctx*)nullptr, CG_ERR_ARG, "cg_create: bad argument (n=%d dim=%d depth=%d spsize=%d tpsize=%d L=%g M=%d); depth >= 2 "
                 "(src/flow.py:52 is ill-formed for depth 1), dim in {2,3}, M >= n", n, dim, depth, spsize, tpsize, L, M);
-    if (!cg_fast_supported(depth, dim, spsize, tpsize))
-        CG_FAIL((cg_ctx*)nullptr, CG_ERR_UNSUPPORTED, "cg_create: no kernel instantiation for depth=%d dim=%d spsize=%d tpsize=%d "
-                "(built: depth 2 with (dim,spsize,tpsize) in cg_dispatch.hpp)", depth, dim, spsize, tpsize);
+    const bool fast_ok = cg_fast_supported(depth, dim, spsize, tpsize);
+    if (!fast_ok && (depth > CG_GEN_MAXDEPTH || spsize > 256 || tpsize > 256))
+        CG_FAIL((cg_ctx*)nullptr, CG_ERR_UNSUPPORTED, "cg_create: depth=%d spsize=%d tpsize=%d exceeds the general path's limits "
+                "(depth <= %d, widths <= 256)", depth, spsize, tpsize, CG_GEN_MAXDEPTH);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) CG_FAIL((cg_ctx*)nullptr, CG_ERR_HIP, "cg_create: no HIP device available (%s)", hipGetErrorString(e));
     if (device < 0 || device >= ndev) CG_FAIL((cg_ctx*)nullptr, CG_ERR_ARG, "cg_create: device %d out of range [0,%d)", device, ndev);
     cg_ctx* c = new cg_ctx();
     c->device = device; c->n = n; c->dim = dim; c->depth = depth; c->hs = spsize; c->ht = tpsize; c->M = M; c->L = L;
-    c->fast = true;
+    c->fast = fast_ok;
+    cg_gen_model_init(c->gm, n, dim, depth, spsize, tpsize, L);
+    c->gw = cg_gen_ws(c->gm);
+    c->P = c->gm.nparam;
+    memset(&c->lay, 0, sizeof(c->lay));
+    if (fast_ok) {
 #define CG_X(D, HS, HT) if (dim == D && spsize == HS && tpsize == HT) c->P = CgFast<D, HS, HT>::NPARAM;
-    CG_FAST_CONFIGS(CG_X)
+        CG_FAST_CONFIGS(CG_X)
 #undef CG_X
-    c->lay = cg_fast_layout(n, dim, spsize, tpsize, true, spsize == 16 && tpsize == 16);
+        c->lay = cg_fast_layout(n, dim, spsize, tpsize, true, spsize == 16 && tpsize == 16);
+    }
     auto fail = [&](const char* what, hipError_t err) {
         g_last_error = std::string("cg_create: ") + what + ": " + hipGetErrorString(err);
         delete c; return CG_ERR_HIP;
@@ -556,6 +664,15 @@ static int check_ready(cg_ctx* c, const char* fn, int B) {
     return CG_OK;
 }
 
+static int ensure_ws(cg_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_cap) return CG_OK;
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
+    CG_HIP(c, hipMalloc(&c->ws, bytes));
+    c->ws_cap = bytes;
+    return CG_OK;
+}
+
 static int run_logpsi(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, int mode,
                       double* logphi, double* hld, double* logpsi_out, double* logp_out, double* z_out, double* J_out) {
     int rc = check_ready(c, fn, B); if (rc) return rc;
@@ -573,6 +690,16 @@ static int run_logpsi(cg_ctx* c, const char* fn, const double* x, const int32_t*
     Arg a6{J_out, nullptr, sizeof(double) * (size_t)B * N * N, false, true};
     Arg* all[] = {&ax, &as, &a1, &a2, &a3, &a4, &a5, &a6};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    if (!c->fast) {
+        const int grid = std::min(B, c->cu_count * 4);
+        if ((rc = ensure_ws(c, sizeof(double) * c->gw.total * grid))) return rc;
+        hipLaunchKernelGGL(k_gen_logpsi, dim3(grid), dim3(256), sizeof(double) * (CG_TAB_DOUBLES + 8), c->stream, c->gm, c->gw,
+                           (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev,
+                           (const int*)as.dev, B, mode, (double*)a1.dev, (double*)a2.dev, (double*)a3.dev, (double*)a4.dev,
+                           (double*)a5.dev, (double*)a6.dev, (double*)c->ws);
+        for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+        return finish(c);
+    }
     const int nt = threads_of(c);
     const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + ((N + 1) & ~1));
     const CgDev m = make_dev(c);
@@ -637,6 +764,18 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
     Arg* all[] = {&ax, &as, &an, &au, &al};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
     CG_HIP(c, hipMemsetAsync(c->d_accept, 0, sizeof(unsigned long long), c->stream));
+    if (!c->fast) {
+        const int grid = std::min(B, c->cu_count * 4);
+        if ((rc = ensure_ws(c, sizeof(double) * c->gw.total * grid))) return rc;
+        hipLaunchKernelGGL(k_gen_mcmc, dim3(grid), dim3(256), sizeof(double) * (CG_TAB_DOUBLES + 8), c->stream, c->gm, c->gw,
+                           (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (double*)ax.dev,
+                           (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset, (const double*)an.dev,
+                           (const double*)au.dev, (double*)al.dev, c->d_accept, (double*)c->ws);
+        for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+        if ((rc = finish(c))) return rc;
+        if (n_accept) return cg_mcmc_accepts(c, n_accept);
+        return CG_OK;
+    }
     const int nt = threads_of(c);
     const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
     const CgDev m = make_dev(c);
@@ -717,14 +856,6 @@ int cg_ewald(cg_ctx* c, const double* x, int B, double* V) {
     return finish(c);
 }
 
-static int ensure_ws(cg_ctx* c, size_t bytes) {
-    if (bytes <= c->ws_cap) return CG_OK;
-    CG_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_cap = 0; }
-    CG_HIP(c, hipMalloc(&c->ws, bytes));
-    c->ws_cap = bytes;
-    return CG_OK;
-}
 
 int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, int mode, const double* v,
                       double* grad, double* lap) {
@@ -744,6 +875,14 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
     const int nt = std::max(threads_of(c), 256);
     const int grid = std::min(B, c->cu_count * 4);
+    if (!c->fast) {
+        if ((rc = ensure_ws(c, sizeof(double) * c->gw.total * grid))) return rc;
+        hipLaunchKernelGGL(k_gen_grad_lap, dim3(grid), dim3(256), sizeof(double) * (CG_TAB_DOUBLES + 256 + 16), c->stream, c->gm, c->gw,
+                           (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev,
+                           (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, (double*)c->ws);
+        for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+        return finish(c);
+    }
     const CgDev m = make_dev(c);
     bool launched = false;
 #define CG_X(D, HS, HT)                                                                                              \
@@ -767,6 +906,8 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
                    const double* w_im, double* g_theta, double* score) {
     int rc = check_ready(c, fn, B); if (rc) return rc;
+    if (!c->fast) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: theta-gradients are implemented for the depth-2 fast path only "
+                          "(depth=%d spsize=%d tpsize=%d runs on the general path)", fn, c->depth, c->hs, c->ht);
     const int n = c->n, N = n * c->dim, P = c->P;
     if (B == 0) {
         if (g_theta && c->ptr_mode == CG_PTR_HOST) memset(g_theta, 0, sizeof(double) * P);

@@ -135,3 +135,37 @@ extern "C" int emu_ewald(int n, int dim, double L, double kappa, double rs, cons
                         : cg_ewald_walker<3>(b, x + (size_t)w * n * dim, n, L, kappa, rs, g32.data(), gk.data(), nG, gmax, g0, lds.data());
     return 0;
 }
+
+// ---- general-depth path (cg_generic.hpp) on the host shim ----
+#include "../../coulombgas_amd/csrc/cg_generic.hpp"
+extern "C" int emu_gen_logpsi(int n, int dim, int depth, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                              const int* sidx, const double* x, int B, double* out3, double* z_out, double* J_out) {
+    CgGenModel m; cg_gen_model_init(m, n, dim, depth, hs, ht, L);
+    CgGenWs w = cg_gen_ws(m);
+    std::vector<double> ws(w.total + 8), spk((size_t)M * dim);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    const int N = n * dim;
+    for (int q = 0; q < B; ++q) {
+        if (z_out || J_out) {
+            CgGen<double>::flow(b, m, theta, x + (size_t)q * N, ws.data() + w.da, true);
+            if (z_out) memcpy(z_out + (size_t)q * N, ws.data() + w.da + m.o_z, sizeof(double) * N);
+            if (J_out) memcpy(J_out + (size_t)q * N * N, ws.data() + w.da + m.o_J, sizeof(double) * N * N);
+        }
+        CgGenK::logpsi(b, m, w, theta, spk.data(), sidx + (size_t)q * n, x + (size_t)q * N, ws.data(), out3[3 * q], out3[3 * q + 1], out3[3 * q + 2]);
+    }
+    return m.nparam;
+}
+extern "C" int emu_gen_grad_laplacian(int n, int dim, int depth, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                                      const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap) {
+    CgGenModel m; cg_gen_model_init(m, n, dim, depth, hs, ht, L);
+    CgGenWs w = cg_gen_ws(m);
+    std::vector<double> ws(w.total + 8), lds(64), spk((size_t)M * dim);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    const int N = n * dim;
+    for (int q = 0; q < B; ++q)
+        CgGenK::grad_laplacian(b, m, w, theta, spk.data(), sidx + (size_t)q * n, x + (size_t)q * N, mode, v ? v + (size_t)q * N : nullptr,
+                               grad + (size_t)q * N * 2, lap + 2 * q, ws.data(), lds.data());
+    return 0;
+}

@@ -143,7 +143,7 @@ def test_wrap_and_errors():
     w = eng.wrap(x)
     assert np.allclose(w, x - s["L"] * np.floor(x / s["L"]), atol=1e-12) and (w >= 0).all() and (w < s["L"]).all()
     with pytest.raises(CoulombGasError):
-        cg.Engine(13, 2, 5, 16, 16, s["L"])                 # depth 5: not instantiated -> loud error, no fallback
+        cg.Engine(13, 2, 9, 16, 16, s["L"])                 # depth 9: beyond the general path's limit -> loud error
     with pytest.raises(IndexError):
         eng.set_params(s["theta"]); eng.logpsi(s["x"], np.full((2, 13), 999))
     # empty batch
@@ -329,3 +329,64 @@ def test_large_n_against_c_oracle(n, Emax, B):
                         p(noise), p(unif), p(lpc))
     assert nacc / (steps * B) == pytest.approx(rate, abs=1e-15)
     assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# general-depth path: the depth-3 networks of the reference's own tests (tests/test_flow.py:42, tests/test_logpsi.py:29)
+# ---------------------------------------------------------------------------------------------
+GCASES = [(7, 3, 3, 16, 16, 1.234), (5, 2, 4, 8, 4, 2.0), (13, 2, 3, 16, 16, None)]
+
+
+@pytest.mark.parametrize("n,dim,depth,hs,ht,L", GCASES)
+def test_general_depth_against_oracle(n, dim, depth, hs, ht, L):
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    from torch.func import jacfwd
+    L = box_length(n, dim) if L is None else L
+    rng = np.random.default_rng(depth)
+    sp = orbitals(dim)
+    B = 2
+    theta = flow_theta(rng, depth, hs, ht, dim, 0.3, 0.1)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0]); v = rng.standard_normal(x.shape)
+    flow = cg.FermiNet(depth, hs, ht, L)
+    rflow = R.FermiNet(depth, hs, ht, L); rparams = R.flow_unravel(R.T(theta), depth, hs, ht, dim)
+    z = flow.apply(theta, None, x)
+    J = flow.engine(n, dim).flow_jacobian(x)
+    logpsi = cg.make_logpsi(flow, sp, L)
+    out = logpsi(x, theta, sidx)
+    r_logpsi = R.make_logpsi(rflow, sp, L)
+    sb = torch.as_tensor(sidx.astype(np.int64))
+    for b in range(B):
+        xb = R.T(x[b])
+        assert np.abs(z[b] - rflow.apply(rparams, xb).numpy()).max() < 1e-12 * max(1.0, np.abs(z[b]).max())
+        Jr = jacfwd(lambda xf: rflow.apply(rparams, xf.reshape(n, dim)).reshape(-1))(xb.reshape(-1)).numpy()
+        assert np.abs(J[b] - Jr).max() < 1e-12
+        ref = r_logpsi(xb, rparams, sb[b]).numpy()
+        assert abs(out[b, 0] - ref[0]) < 1e-11 * max(1.0, abs(ref[0]))
+        assert abs(np.angle(np.exp(1j * (out[b, 1] - ref[1])))) < 1e-11
+    # flow equivariances of tests/test_flow.py:25,32,38 through the GPU path
+    image = rng.integers(-5, 6, size=(n, dim)) * L
+    assert np.allclose(flow.apply(theta, None, x[0] + image), z[0] + image, atol=1e-9)
+    shift = rng.standard_normal(dim)
+    assert np.allclose(flow.apply(theta, None, x[0] + shift), z[0] + shift, atol=1e-9)
+    perm = rng.permutation(n)
+    assert np.allclose(flow.apply(theta, None, x[0][perm]), z[0][perm], atol=1e-12)
+    if n <= 7:
+        r_logphi, r_logjacdet = R.make_logphi_logjacdet(rflow, sp, L)
+        logphi, logjacdet = cg.make_logphi_logjacdet(flow, sp, L)
+        for kw, rkw in ((dict(), dict()), (dict(hutchinson=True, logphi=logphi, logjacdet=logjacdet), dict(hutchinson=True, logphi=r_logphi, logjacdet=r_logjacdet))):
+            g, l = cg.make_logpsi_grad_laplacian(logpsi, **kw)[1](x, theta, sidx, v)
+            gr, lr = R.make_logpsi_grad_laplacian(r_logpsi, **rkw)[1](R.T(x), rparams, sb, R.T(v))
+            assert np.abs(g - gr.numpy()).max() < 1e-10 * np.abs(gr.numpy()).max()
+            assert np.abs(l - lr.numpy()).max() < 1e-9 * np.abs(lr.numpy()).max()
+    # chain with supplied noise
+    steps = 4
+    noise = rng.standard_normal((steps,) + x.shape); unif = rng.uniform(size=(steps, B))
+    logp = cg.make_logp(logpsi)
+    x_new, rate = cg.mcmc(logp.bind(theta, sidx), x, 0, steps, 0.1, noise=noise, unif=unif)
+    r_logp = R.make_logp(r_logpsi)
+    xr, _, rate_r = R.mcmc(lambda xx: r_logp(xx, rparams, sb), R.T(x), R.T(noise), R.T(unif), steps, 0.1)
+    assert rate == pytest.approx(rate_r, abs=1e-15) and np.abs(x_new - xr.numpy()).max() < 1e-12
+    from coulombgas_amd._lib import CoulombGasError
+    with pytest.raises(CoulombGasError):
+        flow.engine(n, dim, sp).param_vjp(x, sidx, np.ones(B), np.zeros(B))     # theta-gradients: depth-2 fast path only

@@ -63,3 +63,29 @@ def test_symmetries_through_device_code():
     pa, pb = np.exp(a[0] + 1j * a[1]), np.exp(bP[0] + 1j * bP[1])
     assert np.allclose(pb, pa) or np.allclose(pb, -pa)
     assert np.allclose(eng.logp(x + shift, s), eng.logp(x, s), atol=1e-9)
+
+
+@pytest.mark.parametrize("n,dim,depth,hs,ht,L", [(7, 3, 3, 16, 16, 1.234), (5, 2, 4, 8, 4, 2.0)])
+def test_general_depth_device_code_vs_c_oracle(n, dim, depth, hs, ht, L):
+    """cg_flow_generic.hpp / cg_generic.hpp (any depth) on the host shim against oracle/cg_oracle.c."""
+    import ctypes as C
+    from tests.common import orbitals, flow_theta, state_indices, walkers
+    from tests.emul_engine import lib as emul_lib
+    from coulombgas_amd.build import build_oracle
+    olib = C.CDLL(build_oracle())
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(3)
+    sp = orbitals(dim)
+    B = 2
+    theta = flow_theta(rng, depth, hs, ht, dim, 0.3, 0.1)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    out = np.zeros((B, 3)); z = np.zeros((B, n, dim)); J = np.zeros((B, n * dim, n * dim))
+    npar = emul_lib().emu_gen_logpsi(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, p(out), p(z), p(J))
+    assert npar == theta.size == olib.cgo_num_params(dim, depth, hs, ht)
+    ref = np.zeros((B, 3)); zr = np.zeros_like(z); Jr = np.zeros_like(J)
+    olib.cgo_logpsi(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, p(ref))
+    olib.cgo_flow(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(x), B, p(zr), p(Jr))
+    assert np.abs(z - zr).max() < 1e-13 and np.abs(J - Jr).max() < 1e-13
+    assert np.abs(out[:, 0] - ref[:, 0]).max() < 1e-11 * np.abs(ref[:, 0]).max()
+    assert np.abs(np.angle(np.exp(1j * (out[:, 1] - ref[:, 1])))).max() < 1e-11
+    assert np.abs(out[:, 2] - ref[:, 2]).max() < 1e-12
