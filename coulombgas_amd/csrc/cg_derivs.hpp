@@ -60,7 +60,7 @@ struct CgDerivs {
         w.Dc = take(2 * (size_t)n * n); w.Dinv = take(2 * (size_t)n * n);
         w.Ta = take(2 * (size_t)D * n * n); w.Kd = take(2 * (size_t)D * D * n);
         w.gz = take(2 * N); w.zbar = take(N); w.Jbar = take(N * N);
-        w.perm = take(N + 2);
+        w.perm = take(N + 42);
         w.adj = take(adj_doubles(n));
         w.gw = take(NP);
         w.total = t;

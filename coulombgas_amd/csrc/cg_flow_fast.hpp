@@ -806,7 +806,8 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias,
     auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
     o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
     o.sg1 = take(n * HS); o.sg2 = take(n * HS);
-    o.perm = take((n * D + 1) / 2 + 1);
+    // results of the wave-level LUs (3 doubles) or, on the LDS LU path, its argmax scratch (>= 40 doubles)
+    o.perm = take((n * D <= 32 && n <= 16) ? 4 : 40);
     o.wt = take(HT * (P + 1) + HS * D);                 // two-particle layer weights [h][bias, P weights], then Wf (HS x D)
     if (!alias) {
         o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);

@@ -17,7 +17,7 @@ static inline CgGenWs cg_gen_ws(const CgGenModel& m) {
     w.Dm = take(2 * n * n); w.Dc = take(2 * n * n); w.Dinv = take(2 * n * n);
     w.Jc = take(N * N); w.Jinv = take(N * N); w.M = take(N * N);
     w.Ta = take(2 * d * n * n); w.Kd = take(2 * d * d * n); w.gz = take(2 * N);
-    w.xj = take(3 * N); w.xc = take(N); w.xp = take(N); w.perm = take(N + 2);
+    w.xj = take(3 * N); w.xc = take(N); w.xp = take(N); w.perm = take(N + 42);
     w.total = t;
     return w;
 }

@@ -8,34 +8,66 @@
 #pragma once
 #include "cg_common.hpp"
 
-// log|det A| of a real N x N matrix (row-major, leading dimension lda) held in LDS.
-// A is destroyed.  perm: int[N] scratch in LDS.  Returns the value in every thread.
-CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* perm, int* sign_out = nullptr) {
-    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
+// Workgroup-wide argmax of a non-negative key (ties -> smallest index).  `scratch` (>= 3*16 doubles worth, LDS):
+// per-wave partial results.  Every thread returns the winning index.
+CG_DEVI int cg_block_argmax(const CgBlk& b, double v, int idx, double* scratch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int oi = __shfl_xor(idx, off);
+        const bool take = (ov > v) || (ov == v && oi < idx);
+        v = take ? ov : v; idx = take ? oi : idx;
+    }
+    const int nw = b.nthr >> 6;
+    if (nw == 1) return idx;
+    int* si = (int*)(scratch + 16);
+    if ((b.tid & 63) == 0) { scratch[b.tid >> 6] = v; si[b.tid >> 6] = idx; }
     b.sync();
+    double bv = scratch[0]; int bi = si[0];
+    for (int w = 1; w < nw; ++w) {
+        const double ov = scratch[w]; const int oi = si[w];
+        const bool take = (ov > bv) || (ov == bv && oi < bi);
+        bv = take ? ov : bv; bi = take ? oi : bi;
+    }
+    b.sync();                      // scratch may be rewritten by the next call
+    return bi;
+#else
+    (void)b; (void)v; (void)scratch;
+    return idx;                    // host shim: one thread has already scanned every candidate
+#endif
+}
+
+// log|det A| of a real N x N matrix (row-major, leading dimension lda) held in LDS (or any memory the workgroup
+// shares).  A is destroyed.  scratch: >= 40 doubles.  getrf-style partial pivoting with physical row swaps; the
+// pivot search is one candidate per thread + a shuffle/LDS argmax (a few hundred cycles per column instead of a
+// serial scan).  Returns the value in every thread.
+CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* scratch_i, int* sign_out = nullptr) {
+    double* scratch = (double*)scratch_i;
     const int TX = b.nthr < 16 ? b.nthr : 16;
     const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
     CgScaledProd prod; prod.init();
     int sgn = 1;
     for (int k = 0; k < N; ++k) {
-        int p = k; double best = -1.0;
-        for (int i = k; i < N; ++i) {
-            double v = fabs(A[perm[i] * lda + k]);
-            if (v > best) { best = v; p = i; }
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = k + b.tid; i < N; i += b.nthr) {
+            const double v = fabs(A[i * lda + k]);
+            if (v > best) { best = v; bi = i; }
         }
-        const int rk = perm[p], rk_old = perm[k];
-        b.sync();                                   // all reads of perm done
-        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
-        const double piv = A[rk * lda + k];
-        if (p != k) sgn = -sgn;
+        int p = cg_block_argmax(b, best, bi, scratch);
+        if (p < k || p >= N) p = k;                 // all-NaN column: keep the diagonal (NaN propagates)
+        if (p != k) {
+            for (int j = k + b.tid; j < N; j += b.nthr) { const double t = A[k * lda + j]; A[k * lda + j] = A[p * lda + j]; A[p * lda + j] = t; }
+            sgn = -sgn;
+        }
+        b.sync();
+        const double piv = A[k * lda + k];
         if (piv < 0) sgn = -sgn;
         prod.mul(piv);
         const double rinv = 1.0 / piv;
-        b.sync();                                   // perm update visible
         for (int i = k + 1 + ty; i < N; i += TY) {
-            const int ri = perm[i];
-            const double l = A[ri * lda + k] * rinv;
-            for (int j = k + 1 + tx; j < N; j += TX) A[ri * lda + j] -= l * A[rk * lda + j];
+            const double l = A[i * lda + k] * rinv;
+            for (int j = k + 1 + tx; j < N; j += TX) A[i * lda + j] -= l * A[k * lda + j];
         }
         b.sync();
     }
@@ -45,40 +77,43 @@ CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* p
 
 // Complex N x N (interleaved re,im; row-major, lda in complex elements) log det:
 // returns log|det| and arg(det) in (-pi, pi]  (jnp.linalg.slogdet + jnp.log(phase), src/slater.py:18-19)
-CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int* perm,
+CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int* scratch_i,
                                   double& logabs, double& arg) {
-    for (int i = b.tid; i < N; i += b.nthr) perm[i] = i;
-    b.sync();
+    double* scratch = (double*)scratch_i;
     const int TX = b.nthr < 16 ? b.nthr : 16;
     const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
     CgCplx pm = {1.0, 0.0}; int pe = 0;             // running product, exponent apart
     for (int k = 0; k < N; ++k) {
-        int p = k; double best = -1.0;
-        for (int i = k; i < N; ++i) {
-            const double* a = A + 2 * (perm[i] * lda + k);
-            double v = a[0] * a[0] + a[1] * a[1];
-            if (v > best) { best = v; p = i; }
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = k + b.tid; i < N; i += b.nthr) {
+            const double* a = A + 2 * (i * lda + k);
+            const double v = a[0] * a[0] + a[1] * a[1];
+            if (v > best) { best = v; bi = i; }
         }
-        const int rk = perm[p], rk_old = perm[k];
+        int p = cg_block_argmax(b, best, bi, scratch);
+        if (p < k || p >= N) p = k;
+        if (p != k) {
+            for (int j = k + b.tid; j < N; j += b.nthr) {
+                double* x = A + 2 * (k * lda + j); double* y = A + 2 * (p * lda + j);
+                const double t0 = x[0], t1 = x[1]; x[0] = y[0]; x[1] = y[1]; y[0] = t0; y[1] = t1;
+            }
+        }
         b.sync();
-        if (b.tid == 0) { perm[p] = rk_old; perm[k] = rk; }
-        CgCplx piv = {A[2 * (rk * lda + k)], A[2 * (rk * lda + k) + 1]};
+        const CgCplx piv = {A[2 * (k * lda + k)], A[2 * (k * lda + k) + 1]};
         pm = cmul(pm, piv);
         if (p != k) { pm.re = -pm.re; pm.im = -pm.im; }
         {   // renormalise
-            int ex; double mx = fmax(fabs(pm.re), fabs(pm.im));
+            int ex; const double mx = fmax(fabs(pm.re), fabs(pm.im));
             (void)frexp(mx, &ex);
             pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex;
         }
         const CgCplx rinv = cinv(piv);
-        b.sync();
         for (int i = k + 1 + ty; i < N; i += TY) {
-            const int ri = perm[i];
-            CgCplx aik = {A[2 * (ri * lda + k)], A[2 * (ri * lda + k) + 1]};
-            CgCplx l = cmul(aik, rinv);
+            const CgCplx aik = {A[2 * (i * lda + k)], A[2 * (i * lda + k) + 1]};
+            const CgCplx l = cmul(aik, rinv);
             for (int j = k + 1 + tx; j < N; j += TX) {
-                double* aij = A + 2 * (ri * lda + j);
-                const double* akj = A + 2 * (rk * lda + j);
+                double* aij = A + 2 * (i * lda + j);
+                const double* akj = A + 2 * (k * lda + j);
                 aij[0] -= l.re * akj[0] - l.im * akj[1];
                 aij[1] -= l.re * akj[1] + l.im * akj[0];
             }
