@@ -781,13 +781,29 @@ struct CgFast {
             b.sync();
             half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
             b.sync();
-        } else
-#endif
+        } else if (o.Dm != o.J) {
+            // mid sizes: single-wave LDS LUs, real on wave 0 and complex on wave 1 concurrently
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            double* res = (double*)perm;
+            const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
+            if (wave == 0) { const double v = cg_wave_lds_lu_logabsdet(lds + o.J, n * D, n * D); if (b.tid == 0) res[0] = v; }
+            if (wave == cw) { double l2, a2; cg_wave_lds_lu_logdet_complex(lds + o.Dm, n, n, l2, a2); if ((b.tid & 63) == 0) { res[1] = l2; res[2] = a2; } }
+            b.sync();
+            half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
+            b.sync();
+        } else {
+            // largest sizes (Slater matrix shares J's LDS): the whole workgroup, one determinant after the other
+            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+        }
+#else
         {
             half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
             slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
             cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
         }
+#endif
         re_phi = la - (double)n * (0.5 * D) * log(L);
         im_phi = ar;
     }
