@@ -109,7 +109,16 @@ def main():
     eng.set_params(theta)
     if args.threads:
         eng.set_block_threads(args.threads)
-    comm = RcclComm(eng, rank, world) if (world > 1 or force_dist) else NullComm()
+    comm_kind = "none"
+    if world > 1 or force_dist:
+        try:
+            comm = RcclComm(eng, rank, world); comm_kind = "rccl via cg_allreduce_mean"
+        except Exception as e:      # keep the scaling run alive: same library (RCCL) through torch.distributed
+            print("bench.py: RcclComm failed (%s); using torch.distributed nccl all_reduce" % e, file=sys.stderr)
+            from coulombgas_amd.comm import TorchDistComm
+            comm = TorchDistComm(device="cuda"); comm_kind = "rccl via torch.distributed"
+    else:
+        comm = NullComm()
 
     eng.device_mode(True)
     d_x = eng.alloc((B, n, dim)).upload(x)
@@ -167,8 +176,14 @@ def main():
         peak_mfma = eng.microbench_fp64(1)
         peak = max(peak_fma, peak_mfma)
         ach = (fl * B * args.mc_steps / k_avg_s / 1e12) if fl else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_n%d_B%d.json" % (n, B))
+        if os.path.exists(tpath):               # HBM bytes per launch from the committed rocprofv3 --pmc passes
+            tj = json.load(open(tpath))
+            if tj.get("mc_steps") == args.mc_steps:
+                traffic = tj["bytes_per_launch"]
         roofline = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": (ach / peak) if ach else None, "traffic": None,
+                    "frac": (ach / peak) if ach else None, "traffic": traffic,
                     "kernel": "k_mcmc", "kernel_avg_ms": k_avg_s * 1e3,
                     "note": "fp64 kernel: peak = measured v_fma_f64 / v_mfma_f64_16x16x4 rate on this GPU (%.1f / %.1f TFLOP/s); "
                             "achieved = SURVEY 8(d) algorithmic %.3g flop/walker-step x %d walker-steps per launch / HIP-event kernel time"
@@ -187,7 +202,7 @@ def main():
                                       "(MCMC chain incl. flow+Jacobian+Slater logp), in-kernel Philox RNG" % (n, args.Emax, B, args.mc_steps, args.mc_stddev),
                           "walkers_per_gpu": B, "mc_steps": args.mc_steps, "threads_per_walker": eng.launch_info()["threads"],
                           "lds_bytes_per_walker": eng.launch_info()["lds_bytes"]},
-               "accept_rate": accept, "finite": ok, "roofline": roofline, "cpu_baseline": cpu}
+               "accept_rate": accept, "finite": ok, "comm": comm_kind, "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if dist is not None:
         comm.close()

@@ -8,6 +8,7 @@
                   multi-process host logic
 """
 import ctypes as C
+import os
 import numpy as np
 
 
@@ -22,14 +23,20 @@ class NullComm:
 
 
 class TorchDistComm:
-    def __init__(self):
+    def __init__(self, device=None):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device          # None: host tensors (gloo); "cuda": nccl(=RCCL) through torch
 
     def pmean(self, a):
         import torch
         t = torch.from_numpy(np.array(a, dtype=np.float64, ndmin=1, copy=True))
+        if self.device is not None:
+            t = t.to(self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            out = (t / self.world).cpu().numpy()
+            return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         out = (t / self.world).numpy()
         return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
@@ -48,7 +55,7 @@ class RcclComm:
         if unique_id is None:
             if rank == 0:
                 check(lib().cg_comm_unique_id(uid), None)
-            if world == 1:
+            if world == 1 and exchange is None and os.environ.get("CG_FORCE_DIST") != "1":
                 raw = bytes(uid.raw)
             else:
                 if exchange is None:
