@@ -92,23 +92,36 @@ struct CgFast {
     //   A: lane l holds A[row = l & 15][k = l >> 4];  B: B[k = l >> 4][col = l & 15];
     //   C/D: 4 doubles per lane, D[row = (l >> 4) + 4 r][col = l & 15]   (f64 layout, not the f32 one)
     // ---------------------------------------------------------------------------------------
+    // Per-lane weight columns kept in VGPRs for the whole chain (the pair passes use them in every iteration).
+    // The MFMA B-operand fragments are (re)loaded from theta right before each dense phase instead: they are the
+    // same 8.6 KB for every wave (L2/L1 hits), whereas keeping them live across the LUs made the compiler spill
+    // them to per-wave scratch (measured: 6 GB of memory-side traffic per launch).
     struct WFrag {
-        double w0[2];      // W0 (P x 16), K padded to 8
-        double b0, b2;     // biases of the two one-particle layers, by column
-        double wacb[12];   // [Wa; Wc; Wb] (48 x 16): u2 = s1 Wa + m1 Wc + gbar Wb
-        double wf[4];      // Wf (16 x D), columns >= D zero
-        double bf;         // final bias by column (0 beyond D)
-        double ja[4], jb[4], jc[4];   // Wa^T, Wb^T, Wc^T (k = h, col = g): R_i W_x^T
-        double w0t[4];     // W0^T (k = g, col = f < P)
+        const double* th;
         double tw[P + 1];  // two-particle layer column h = lane & 15: bias, then P weights  (pair-primal pass)
         double gw[P];      // W0 column h = lane & 15                                        (G pass)
     };
+    struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
+    struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
+    struct DenseU { double w0t[4]; };
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef double d4_t __attribute__((ext_vector_type(4)));
     static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w) {
+    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w) { w.th = th; }
+    static __device__ __forceinline__ void load_pair_cols(const double* __restrict__ th_in, WFrag& w) {
+        const double* th = th_in;
+        asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
+        const int col = threadIdx.x & 15;
+        w.th = th_in;
+        w.tw[0] = th[o_t0b + col];
+#pragma unroll
+        for (int f = 0; f < P; ++f) { w.tw[1 + f] = th[o_t0w + f * HT + col]; w.gw[f] = th[o_W0 + f * HS + col]; }
+    }
+    static __device__ __forceinline__ void load_dense_p(const double* __restrict__ th_in, DenseP& w) {
+        const double* th = th_in;
+        asm volatile("" : "+s"(th));      // opaque to LICM: keep these loads inside the evaluation, not hoisted + spilled
         const int l = threadIdx.x & 63, col = l & 15, kq = l >> 4;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) { const int f = 4 * ks + kq; w.w0[ks] = f < P ? th[o_W0 + f * HS + col] : 0.0; }
@@ -120,15 +133,27 @@ struct CgFast {
             w.wacb[4 + ks] = th[o_Wc + k * HS + col];
             w.wacb[8 + ks] = th[o_Wb + k * HS + col];
             w.wf[ks] = col < D ? th[o_fw + k * D + col] : 0.0;
+        }
+        w.bf = col < D ? th[o_fb + col] : 0.0;
+    }
+    static __device__ __forceinline__ void load_dense_j(const double* __restrict__ th_in, DenseJ& w) {
+        const double* th = th_in;
+        asm volatile("" : "+s"(th));      // opaque to LICM: keep these loads inside the evaluation, not hoisted + spilled
+        const int l = threadIdx.x & 63, col = l & 15, kq = l >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = 4 * ks + kq;
             w.ja[ks] = th[o_Wa + col * HS + k];            // B[k = h][col = g] = Wa[g][h]
             w.jb[ks] = th[o_Wb + col * HS + k];
             w.jc[ks] = th[o_Wc + col * HS + k];
-            w.w0t[ks] = col < P ? th[o_W0 + col * HS + k] : 0.0;   // B[k = g][col = f] = W0[f][g]
         }
-        w.bf = col < D ? th[o_fb + col] : 0.0;
-        w.tw[0] = th[o_t0b + col];
+    }
+    static __device__ __forceinline__ void load_dense_u(const double* __restrict__ th_in, DenseU& w) {
+        const double* th = th_in;
+        asm volatile("" : "+s"(th));      // opaque to LICM: keep these loads inside the evaluation, not hoisted + spilled
+        const int l = threadIdx.x & 63, col = l & 15, kq = l >> 4;
 #pragma unroll
-        for (int f = 0; f < P; ++f) { w.tw[1 + f] = th[o_t0w + f * HT + col]; w.gw[f] = th[o_W0 + f * HS + col]; }
+        for (int ks = 0; ks < 4; ++ks) w.w0t[ks] = col < P ? th[o_W0 + col * HS + 4 * ks + kq] : 0.0;   // B[k = g][col = f] = W0[f][g]
     }
     // broadcast lane LANE of every 16-lane DPP row to the whole row (row_newbcast, gfx90a+)
     template <int LANE>
@@ -182,7 +207,8 @@ struct CgFast {
         f.del = sqrt(d2);
         f.rdel = (ok && i != j) ? 1.0 / f.del : 0.0;
     }
-    static __device__ __forceinline__ void primal_pairs_dpp(const CgBlk& b, const WFrag& w, int n, double* lds, const CgFastLds& o) {
+    static __device__ __forceinline__ void primal_pairs_dpp(const CgBlk& b, const WFrag& wfr, int n, double* lds, const CgFastLds& o) {
+        WFrag w; load_pair_cols(wfr.th, w);
         const double *sh = lds + o.sh, *ch = lds + o.ch;
         double *m0 = lds + o.m0, *m1 = lds + o.m1;
         const double rn = 1.0 / (double)n;
@@ -219,7 +245,8 @@ struct CgFast {
             }
         }
     }
-    static __device__ __forceinline__ void g_pass_dpp(const CgBlk& b, const WFrag& w, int n, double L, double* lds, const CgFastLds& o) {
+    static __device__ __forceinline__ void g_pass_dpp(const CgBlk& b, const WFrag& wfr, int n, double L, double* lds, const CgFastLds& o) {
+        WFrag w; load_pair_cols(wfr.th, w);
         const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1;
         double* G = lds + o.G;
         const double rn = 1.0 / (double)n;
@@ -243,8 +270,9 @@ struct CgFast {
         }
     }
     // dense part of primal(): needs m0, m1 in LDS; fills s1 sg1 sg2 s2 z.  Executed by wave 0; others wait.
-    static __device__ __forceinline__ void primal_dense_mfma(const CgBlk& b, const WFrag& w, const double* x, int n,
+    static __device__ __forceinline__ void primal_dense_mfma(const CgBlk& b, const WFrag& wfr, const double* x, int n,
                                                              double* lds, const CgFastLds& o) {
+        DenseP w; load_dense_p(wfr.th, w);
         double *m0 = lds + o.m0, *s1 = lds + o.s1, *sg1 = lds + o.sg1, *m1 = lds + o.m1, *gbar = lds + o.gbar,
                *sg2 = lds + o.sg2, *s2 = lds + o.s2, *z = lds + o.z;
         const int l = b.tid & 63, col = l & 15, kq = l >> 4;
@@ -319,8 +347,9 @@ struct CgFast {
     }
     // U, Bm (which = 0) or V (which = 1) of jacobian(): rows r = (i,a).  wfl: Wf (HS x D) staged in LDS.
     template <int WHICH>
-    static __device__ __forceinline__ void jac_factors_mfma(const CgBlk& b, const WFrag& w, int n, double* lds,
+    static __device__ __forceinline__ void jac_factors_mfma(const CgBlk& b, const WFrag& wfr, int n, double* lds,
                                                             const CgFastLds& o, const double* wfl) {
+        DenseJ w; load_dense_j(wfr.th, w);
         const double* sg2 = lds + o.sg2;
         double *U = lds + o.U, *V = lds + o.V, *Bm = lds + o.Bm;
         const int l = b.tid & 63, col = l & 15, kq = l >> 4;
@@ -382,7 +411,8 @@ struct CgFast {
         }
     }
     // Up = (1/n) (U diag sg1) W0^T
-    static __device__ __forceinline__ void jac_up_mfma(const CgBlk& b, const WFrag& w, int n, double* lds, const CgFastLds& o) {
+    static __device__ __forceinline__ void jac_up_mfma(const CgBlk& b, const WFrag& wfr, int n, double* lds, const CgFastLds& o) {
+        DenseU w; load_dense_u(wfr.th, w);
         const double *sg1 = lds + o.sg1, *U = lds + o.U;
         double* Up = lds + o.Up;
         const int l = b.tid & 63, col = l & 15, kq = l >> 4;
@@ -772,6 +802,7 @@ struct CgFast {
                 const double v = NN == 26 ? cg_wave_lu_logabsdet<26>(lds + o.J, NN, NN) : cg_wave_lu_logabsdet<32>(lds + o.J, NN, NN);
                 if (b.tid == 0) res[0] = v;
             }
+            __builtin_amdgcn_sched_barrier(0);         // keep the two register-resident factorisations apart (spills otherwise)
             if (wave == cw) {
                 double l2, a2;
                 if (n == 13) cg_wave_lu_logdet_complex<13>(lds + o.Dm, n, n, l2, a2);
