@@ -126,11 +126,33 @@ CG_DEVI double sigmoid_only(double u) {
     double lg, r; cg_log_rcp_12(1.0 + e, lg, r);
     return (u >= 0.0) ? r : e * r;
 }
+// log(w) only, w in [1, 2]  (same table as cg_log_rcp_12, without the reciprocal)
+CG_DEVI double cg_log_12(double w) {
+    const bool two = w >= 2.0;
+    const double m = two ? 1.0 : w;
+#if defined(__HIPCC__)
+    const int hi = __double2hiint(m);
+#else
+    long long bits; memcpy(&bits, &m, 8); const int hi = (int)(bits >> 32);
+#endif
+    const int i = (hi >> 14) & 63;
+    const double inv = CG_TAB[32 + 2 * i], lc = CG_TAB[32 + 2 * i + 1];
+    const double r = fma(m, inv, -1.0);
+    double p = 1.0 / 7.0;
+    p = fma(p, r, -1.0 / 6.0);
+    p = fma(p, r, 0.2);
+    p = fma(p, r, -0.25);
+    p = fma(p, r, 1.0 / 3.0);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    const double l = fma(p, r, lc);
+    return two ? 0.693147180559945309417232121458 : l;
+}
 CG_DEVI double softplus_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));
     const double w = 1.0 + e;
-    double lg, r; cg_log_rcp_12(w, lg, r);
-    return fmax(u, 0.0) + fma(e - (w - 1.0), r, lg);
+    // log1p(e) = log(w) + (e - (w - 1))/w; the correction is <= 2^-53, so 1/w ~ 1 - e/2 is exact enough for it
+    return fmax(u, 0.0) + fma(e - (w - 1.0), fma(-0.5, e, 1.0), cg_log_12(w));
 }
 
 // running product with exponent kept apart (avoids n logs per determinant and over/underflow)

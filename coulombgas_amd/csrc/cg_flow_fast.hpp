@@ -178,12 +178,7 @@ struct CgFast {
                                                             double& acc, double& raw) {
         if constexpr (JJ < 16) {
             if (jbase + JJ < n) {                                  // wave-uniform
-                PF6 pf; pf_bcast<JJ>(mine, pf);
-                if (i == jbase + JJ) {                             // exact diagonal feature (src/flow.py:25)
-#pragma unroll
-                    for (int a = 0; a < D; ++a) { pf.c2[a] = 1.0; pf.s2[a] = 0.0; }
-                    pf.del = 0.0;
-                }
+                PF6 pf; pf_bcast<JJ>(mine, pf);                    // (the owner lane already holds the exact diagonal feature)
                 double u = w.tw[0] + w.tw[1 + 2 * D] * pf.del;
 #pragma unroll
                 for (int a = 0; a < D; ++a) u += w.tw[1 + a] * pf.c2[a] + w.tw[1 + D + a] * pf.s2[a];
@@ -206,6 +201,11 @@ struct CgFast {
         }
         f.del = sqrt(d2);
         f.rdel = (ok && i != j) ? 1.0 / f.del : 0.0;
+        if (i == j) {                                          // exact diagonal feature [1..1, 0..0, 0] (src/flow.py:25)
+#pragma unroll
+            for (int a = 0; a < D; ++a) { f.c2[a] = 1.0; f.s2[a] = 0.0; }
+            f.del = 0.0;
+        }
     }
     static __device__ __forceinline__ void primal_pairs_dpp(const CgBlk& b, const WFrag& wfr, int n, double* lds, const CgFastLds& o) {
         WFrag w; load_pair_cols(wfr.th, w);
