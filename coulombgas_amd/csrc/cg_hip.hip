@@ -165,8 +165,11 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 }
 
 // grad / Laplacian of log Psi w.r.t. x (cg_derivs.hpp); per-walker workspace in HBM.
+#ifndef CG_DERIV_WAVES
+#define CG_DERIV_WAVES 3
+#endif
 template <int D, int HS, int HT>
-__global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
                            double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
@@ -183,7 +186,7 @@ __global__ void k_grad_lap(CgDev m, const double* __restrict__ theta, const doub
 }
 
 template <int D, int HS, int HT>
-__global__ void k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+__global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
                             double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
@@ -873,8 +876,8 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     Arg al{lap, nullptr, sizeof(double) * (size_t)B * 2, false, true};
     Arg* all[] = {&ax, &as, &av, &ag, &al};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    const int nt = std::max(threads_of(c), 256);
-    const int grid = std::min(B, c->cu_count * 4);
+    const int nt = 256;
+    const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
     if (!c->fast) {
         if ((rc = ensure_ws(c, sizeof(double) * c->gw.total * grid))) return rc;
         hipLaunchKernelGGL(k_gen_grad_lap, dim3(grid), dim3(256), sizeof(double) * (CG_TAB_DOUBLES + 256 + 16), c->stream, c->gm, c->gw,
@@ -924,8 +927,8 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     Arg asc{score, nullptr, sizeof(double) * (size_t)B * P * 2, false, true};
     Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    const int nt = std::max(threads_of(c), 256);
-    const int grid = std::min(B, c->cu_count * 4);
+    const int nt = 256;
+    const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
     double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
     if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
     const CgDev m = make_dev(c);
