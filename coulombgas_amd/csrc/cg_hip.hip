@@ -171,7 +171,7 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 template <int D, int HS, int HT>
 __global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
-                           double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
+                           double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
@@ -189,7 +189,7 @@ template <int D, int HS, int HT>
 __global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
-                            double* __restrict__ ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
+                            double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_gen_logpsi(CgGenModel m, CgGenWs w, con
                                                     const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                                                     double* __restrict__ logphi, double* __restrict__ hld, double* __restrict__ logpsi_out,
                                                     double* __restrict__ logp_out, double* __restrict__ z_out, double* __restrict__ J_out,
-                                                    double* __restrict__ wsall) {
+                                                    double* wsall) {
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     __syncthreads();
@@ -260,7 +260,7 @@ __global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const
                                                   const int* __restrict__ sidx, int B, int steps, double stddev, uint64_t seed,
                                                   uint64_t walker_offset, const double* __restrict__ noise, const double* __restrict__ unif,
                                                   double* __restrict__ logp_out, unsigned long long* __restrict__ n_accept,
-                                                  double* __restrict__ wsall) {
+                                                  double* wsall) {
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     __syncthreads();
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) k_gen_grad_lap(CgGenModel m, CgGenWs w, c
                                                       const double* __restrict__ spk, const double* __restrict__ tab,
                                                       const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                                                       const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
-                                                      double* __restrict__ wsall) {
+                                                      double* wsall) {
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     __syncthreads();
