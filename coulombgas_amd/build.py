@@ -37,6 +37,16 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+def build_diag(name, flags):
+    """Diagnostic A/B builds of the same ABI (tools/): lib/diag/lib<name>.so, selected with COULOMBGAS_HIP_LIB."""
+    out = os.path.join(LIBDIR, "diag", "lib%s.so" % name)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"] + list(flags) +
+         ["-o", out, os.path.join(CSRC, "cg_hip.hip"), "-ldl"])
+    return out
+
+
 def build_emul(force=False):
     src = os.path.join(ROOT, "tests", "host_emul", "cg_emul.cpp")
     out = os.path.join(ROOT, "tests", "host_emul", "libcg_emul.so")
@@ -58,5 +68,7 @@ def build_oracle(force=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--diag":       # python -m coulombgas_amd.build --diag NAME -DFLAG ...
+        build_diag(sys.argv[2], sys.argv[3:]); sys.exit(0)
     f = "--force" in sys.argv
     build_hip(f); build_emul(f); build_oracle(f)

@@ -33,6 +33,42 @@ struct CgBlk {
 
 #define CG_PI 3.14159265358979323846264338327950288
 
+// Diagnostic builds only (-DCG_STAMPS, tools/stamps.py): lane 0 of every wave charges the s_memtime cycles between
+// consecutive stamps to a per-phase device counter (CG_STAMP(k) ends phase k and starts phase k+1).  Compiles to
+// nothing in the product build.
+#if defined(CG_STAMPS) && defined(__HIPCC__)
+__device__ unsigned long long cg_stamp_acc[64];
+__shared__ unsigned long long cg_stamp_lds[32];       // per-workgroup accumulation (no global contention)
+static __device__ __forceinline__ void cg_stamp_at(int end_k, int start_k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long t = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) {
+        if (end_k >= 0) atomicAdd(&cg_stamp_lds[end_k], t);
+        if (start_k >= 0) atomicAdd(&cg_stamp_lds[start_k], 0ull - t);
+    }
+#endif
+}
+static __device__ __forceinline__ void cg_stamp_init() {
+    if (threadIdx.x < 32) cg_stamp_lds[threadIdx.x] = 0;
+    __syncthreads();
+}
+static __device__ __forceinline__ void cg_stamp_flush() {
+    __syncthreads();
+    if (threadIdx.x < 32 && cg_stamp_lds[threadIdx.x]) atomicAdd(&cg_stamp_acc[threadIdx.x], cg_stamp_lds[threadIdx.x]);
+}
+#define CG_STAMP_INIT cg_stamp_init();
+#define CG_STAMP_FLUSH cg_stamp_flush();
+#define CG_STAMP_START(k) cg_stamp_at(-1, k);
+#define CG_STAMP(k) cg_stamp_at(k, (k) + 1);
+#define CG_STAMP_END(k) cg_stamp_at(k, -1);
+#else
+#define CG_STAMP_INIT
+#define CG_STAMP_FLUSH
+#define CG_STAMP_START(k)
+#define CG_STAMP(k)
+#define CG_STAMP_END(k)
+#endif
+
 // ---- fp64 transcendentals specialised for the flow's activations ---------------------------------------------
 // gfx950 has no f64 exp/log instructions.  The generic ocml routines carry range / special-case handling these
 // call sites do not need, and a plain polynomial evaluation costs ~65 VALU instructions per softplus.  The versions

@@ -30,7 +30,7 @@
 
 // Offsets (in doubles) into the per-walker LDS arena; filled by the host (cg_layout.hpp).
 struct CgFastLds {
-    int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, wt, total;
+    int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, wt, lus, total;
     int wave_lu;      // 1: both determinants by the wave-level register LU (N <= 32, n <= 16, Dm not on J)
 };
 
@@ -199,8 +199,9 @@ struct CgFast {
             const double s = si * cj - ci * sj, c = ci * cj + si * sj;
             f.s2[a] = 2.0 * (s * c); f.c2[a] = 1.0 - 2.0 * (s * s); d2 += s * s;
         }
-        f.del = sqrt(d2);
-        f.rdel = (ok && i != j) ? 1.0 / f.del : 0.0;
+        double rd;
+        cg_fast_sqrt_rsqrt(d2, f.del, rd);
+        f.rdel = (ok && i != j) ? rd : 0.0;
         if (i == j) {                                          // exact diagonal feature [1..1, 0..0, 0] (src/flow.py:25)
 #pragma unroll
             for (int a = 0; a < D; ++a) { f.c2[a] = 1.0; f.s2[a] = 0.0; }
@@ -451,20 +452,26 @@ struct CgFast {
         }
         for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
         b.sync();
+        CG_STAMP(4)
         jac_factors_mfma<0>(b, w, n, lds, o, wfl);
+        CG_STAMP(5)
         g_pass_dpp(b, w, n, L, lds, o);
         b.sync();
+        CG_STAMP(6)
         jac_up_mfma(b, w, n, lds, o);
         b.sync();
+        CG_STAMP(7)
         jac_bg_mfma(b, n, lds, o);
         b.sync();
+        CG_STAMP(8)
         jac_factors_mfma<1>(b, w, n, lds, o, wfl);
         b.sync();
+        CG_STAMP(9)
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, k = e - i * n;
             if (i == k) continue;
-            PairF pf; pairfeat(sh, ch, i, k, pf);
-            const double rdel = 1.0 / pf.del;
+            PF6 pf; own_pair(sh, ch, i, k, true, pf);
+            const double rdel = pf.rdel;
             double tc[D], ts[D], td[D];
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * (pf.s2[bb] * rdel); }
@@ -501,6 +508,7 @@ struct CgFast {
                 for (int bb = 0; bb < D; ++bb) J[(i * D + a) * N + k * D + bb] = Jb[a][bb];
         }
         b.sync();
+        CG_STAMP(10)
         for (int e = b.tid; e < n * D * D; e += b.nthr) {
             const int i = e / (D * D), r = e - i * (D * D), a = r / D, bb = r - a * D;
             double v = (a == bb) ? 1.0 : 0.0;
@@ -509,6 +517,7 @@ struct CgFast {
             J[(i * D + a) * N + i * D + bb] = v;
         }
         b.sync();
+        CG_STAMP(11)
     }
 #endif
 
@@ -527,6 +536,7 @@ struct CgFast {
             sh[e] = s; ch[e] = c;
         }
         b.sync();
+        CG_STAMP(1)
         bool pairs_done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
@@ -563,9 +573,10 @@ struct CgFast {
             if (h < P) m0[i * P + h] = raw * rn;
         }
         b.sync();
+        CG_STAMP(2)
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
-            if (wf) { primal_dense_mfma(b, *wf, (const double*)x, n, (double*)lds, o); return; }
+            if (wf) { primal_dense_mfma(b, *wf, (const double*)x, n, (double*)lds, o); CG_STAMP(3) return; }
         }
 #endif
         // layer 0 of the one-particle stream: u1_i = W0^T m0_i + b0 (s0 = 0, src/flow.py:16-18,45)
@@ -795,23 +806,27 @@ struct CgFast {
             // Slater matrix first (its slot does not overlap J), then the two LUs run barrier-free in registers:
             // wave 0 the real Jacobian, wave 1 (if the workgroup has one) the complex Slater matrix, concurrently.
             slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            CG_STAMP(12)
             double* res = (double*)perm;
             const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
             if (wave == 0) {
                 const int NN = n * D;
-                const double v = NN == 26 ? cg_wave_lu_logabsdet<26>(lds + o.J, NN, NN) : cg_wave_lu_logabsdet<32>(lds + o.J, NN, NN);
+                const double v = NN == 26 ? cg_wave_lu2_logabsdet<26>(lds + o.J, NN, NN, lds + o.lus)
+                                          : cg_wave_lu2_logabsdet<32>(lds + o.J, NN, NN, lds + o.lus);
                 if (b.tid == 0) res[0] = v;
             }
+            CG_STAMP(13)
             __builtin_amdgcn_sched_barrier(0);         // keep the two register-resident factorisations apart (spills otherwise)
             if (wave == cw) {
                 double l2, a2;
-                if (n == 13) cg_wave_lu_logdet_complex<13>(lds + o.Dm, n, n, l2, a2);
-                else cg_wave_lu_logdet_complex<16>(lds + o.Dm, n, n, l2, a2);
+                if (n == 13) cg_wave_lu2_logdet_complex<13>(lds + o.Dm, n, n, lds + o.lus + 32, l2, a2);
+                else cg_wave_lu2_logdet_complex<16>(lds + o.Dm, n, n, lds + o.lus + 32, l2, a2);
                 if ((b.tid & 63) == 0) { res[1] = l2; res[2] = a2; }
             }
             b.sync();
             half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
             b.sync();
+            CG_STAMP(14)
         } else if (o.Dm != o.J) {
             // mid sizes: single-wave LDS LUs, real on wave 0 and complex on wave 1 concurrently
             slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
@@ -861,6 +876,7 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias,
         o.U = take(n * D * HS); o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
         o.J = take(n * D * n * D);
         o.Dm = take(2 * n * n);
+        o.lus = take(64);
         o.total = t;
         o.wave_lu = (n * D <= 32 && n <= 16) ? 1 : 0;
         return o;
@@ -880,7 +896,9 @@ static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias,
     if (n * D * HS > n * D * n * D) { o.U = take(n * D * HS); }
     if (end_jac - base >= 2 * n * n) o.Dm = base;       // Slater matrix over the dead per-particle factors
     else o.Dm = o.J;                                    // large n: over J after its LU (2 n^2 <= (n D)^2)
-    o.wave_lu = (n * D <= 32 && n <= 16 && o.Dm != o.J && (n * D + 1) / 2 + 1 >= 3) ? 1 : 0;
+    // pivot-row scratch of the wave-level LUs (2 x 32 doubles): behind the Slater matrix, still inside the dead factors
+    o.lus = base + ((2 * n * n + 1) & ~1);
+    o.wave_lu = (n * D <= 32 && n <= 16 && o.Dm != o.J && o.lus + 64 <= end_jac) ? 1 : 0;
     o.total = t;
     return o;
 }

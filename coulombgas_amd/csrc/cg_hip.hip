@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
     double* xc = lds + m.lay.total;          // current configuration
     double* xp = xc + ((N + 1) & ~1);        // proposal
     int* flag = (int*)(xp + ((N + 1) & ~1));
+    CG_STAMP_INIT
     typename F::WFrag wfrag; const typename F::WFrag* wf = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (HS == 16 && HT == 16) { F::load_frags(theta, wfrag); wf = &wfrag; }
@@ -104,6 +105,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
         // step -1 evaluates logp of the initial configuration (src/MCMC.py:36) through the SAME call site as the
         // proposals, so that the (large, unrolled) log Psi code exists once in the instruction stream.
         for (int s = -1; s < steps; ++s) {
+            CG_STAMP_START(0)
             for (int e = b.tid; e < N; e += b.nthr) {
                 double g = 0.0;
                 if (s >= 0) g = noise ? noise[((size_t)s * B + w) * N + e]
@@ -111,6 +113,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
                 xp[e] = xc[e] + stddev * g;
             }
             b.sync();
+            CG_STAMP(0)
             double re, im, h;
             F::logpsi(b, theta, xp, spk, si, n, m.L, lds, m.lay, re, im, h, wf);
             const double lp = 2.0 * (re + h);
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
                 if (s >= 0) ++nacc;
             }
             b.sync();
+            CG_STAMP_END(15)
         }
         for (int e = b.tid; e < N; e += b.nthr) x[(size_t)w * N + e] = xc[e];
         if (b.tid == 0) {
@@ -139,6 +143,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
         }
         b.sync();
     }
+    CG_STAMP_FLUSH
 }
 
 template <int D>
@@ -275,6 +280,7 @@ __global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const
         double logp = 0.0;
         unsigned int nacc = 0;
         for (int s = -1; s < steps; ++s) {
+            CG_STAMP_START(0)
             for (int e = b.tid; e < N; e += b.nthr) {
                 double g = 0.0;
                 if (s >= 0) g = noise ? noise[((size_t)s * B + q) * N + e] : cg_philox_normal(seed, walker_offset + q, (uint32_t)s, (uint32_t)e);
@@ -984,6 +990,17 @@ int cg_microbench_fp64(cg_ctx* c, int which, double* tflops) {
     *tflops = flops / (ms * 1e-3) / 1e12;
     return CG_OK;
 }
+
+#if defined(CG_STAMPS)
+/* diagnostic builds only: read (and clear) the per-phase cycle counters of cg_common.hpp */
+int cg_debug_stamps(cg_ctx* c, unsigned long long* out64, int clear) {
+    if (!c || !out64) return CG_ERR_ARG;
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    CG_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(cg_stamp_acc), sizeof(unsigned long long) * 64));
+    if (clear) { unsigned long long z[64] = {0}; CG_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(cg_stamp_acc), z, sizeof(z))); }
+    return CG_OK;
+}
+#endif
 
 int cg_scale_dev(cg_ctx* c, double* buf, size_t count, double s) {
     if (!c) return CG_ERR_ARG;

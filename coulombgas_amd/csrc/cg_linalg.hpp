@@ -238,11 +238,7 @@ CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, doubl
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Wave-level register LU (gfx950 only): one wave64 factorises one small matrix held one ROW PER LANE in VGPRs.
-// No LDS traffic, no barriers: the pivot row is broadcast with v_readlane (the pivot lane index is wave-uniform),
-// rows are never swapped (a lane that has served as pivot just stops updating), the pivot search is a DPP max on
-// the high word of |a_ik| (a near-maximal pivot is as good as the maximal one) + ballot.
-// Used by the sampler for N = n*d <= 32 (real Jacobian) and n <= 16 (complex Slater matrix).
+// Wave-level helpers (gfx950 only) shared by the register / LDS LUs below.
 // ------------------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double cg_readlane_f64(double v, int lane) {
@@ -262,80 +258,153 @@ __device__ __forceinline__ unsigned cg_wave_max_u32(unsigned v) {
     return max(max(a, b), max(c, d));
 }
 
-// log|det A|, A: N x N real in LDS (row-major, lda).  Must be called by all 64 lanes of ONE wave.
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
+// Wave-level LU, 2-D lane layout (gfx950): the sampler's determinants at N = n*d <= 32, n <= 16.
+//   real    : lane = 2 r + c holds row r, columns j = 2 m + c  (m < NMAX/2)   -> 2 N of 64 lanes busy, N/2 doubles each
+//   complex : lane = 4 r + c holds row r, columns j = 4 m + c  (m < 4)        -> 4 n of 64 lanes busy
+// Per column: the candidate column entry is shared inside the lane pair / quad by DPP quad_perm, the pivot is
+// found by a DPP max on the high word of |a_rk| + ballot (a near-maximal pivot is as good as the maximal one), the
+// pivot row's tail goes through a small LDS scratch (written by the lanes that own it, read back by every lane with
+// ds_read2_b64: LDS executes one wave's instructions in order, so no barrier) instead of two v_readlane per element,
+// and reciprocals are v_rcp_f64 + two Newton steps instead of IEEE divisions.  Rows are never swapped: a row that
+// has served as pivot stops updating.  Must be called by all 64 lanes of ONE wave.
+// ------------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// 1/x to ~1 ulp (x = 0 -> +-inf like the division it replaces)
+__device__ __forceinline__ double cg_fast_rcp(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r0, 1.0);
+    double r = fma(r0, e, r0);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return fabs(x) > 0.0 ? r : r0;
+}
+// sqrt(x) and 1/sqrt(x) for x > 0 (normal range) from v_rsq_f64 + two Newton steps
+__device__ __forceinline__ void cg_fast_sqrt_rsqrt(double x, double& sq, double& rs) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    const double g = x * y;                           // sqrt(x) with one correction step: g + (x - g^2) y / 2
+    const double q = fma(fma(-g, g, x), 0.5 * y, g);
+    const bool pos = x > 0.0;                         // x = 0: sqrt 0, 1/sqrt inf (as sqrt() and the division would give)
+    sq = pos ? q : x;
+    rs = pos ? y : __builtin_amdgcn_rsq(x);
+}
+template <int CTRL>
+__device__ __forceinline__ double cg_dpp_f64(double v) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// log|det A|, A: N x N real in LDS (row-major, lda), N <= NMAX <= 32 (NMAX even).  scr: 32 doubles of LDS.
 template <int NMAX>
-__device__ __forceinline__ double cg_wave_lu_logabsdet(const double* A, int N, int lda) {
-    const int lane = threadIdx.x & 63;
-    double a[NMAX];
+__device__ __forceinline__ double cg_wave_lu2_logabsdet(const double* A, int N, int lda, double* scr) {
+    constexpr int MH = NMAX / 2, MHP = (MH + 1) & ~1;
+    const int lane = threadIdx.x & 63, r = lane >> 1, c = lane & 1;
+    double a[MH];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) a[j] = (lane < N && j < N) ? A[lane * lda + j] : 0.0;
-    bool done = lane >= N;
+    for (int m = 0; m < MH; ++m) { const int j = 2 * m + c; a[m] = (r < N && j < N) ? A[r * lda + j] : 0.0; }
+    bool done = r >= N;
+    double* mine = scr + c * MHP;
     CgScaledProd prod; prod.init();
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
         if (k < N) {
-            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(a[k])) >> 32) + 1u;
+            const int ck = k & 1, mk = k >> 1;
+            const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);      // column k of this lane's row
+            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(ak)) >> 32) + 1u;
             const unsigned mx = cg_wave_max_u32(key);
             const unsigned long long mask = __ballot(key == mx && !done);
-            const int p = mask ? (int)__builtin_ctzll(mask) : k;        // singular column: any row (pivot 0 -> -inf)
-            const double piv = cg_readlane_f64(a[k], p);
+            const int p = mask ? (int)__builtin_ctzll(mask) : 2 * k;     // singular column: any row (pivot 0 -> -inf)
+            const double piv = cg_readlane_f64(ak, p);
             prod.mul(piv);
-            const double rinv = 1.0 / piv;
-            const double l = (done || lane == p) ? 0.0 : a[k] * rinv;
+            const double rinv = cg_fast_rcp(piv);
+            const bool isp = r == (p >> 1);
+            const double l = (done || isp) ? 0.0 : ak * rinv;
+            const int m0 = ck ? mk + 1 : mk;          // first local column that still lies right of column k (or is k itself)
+            if (isp) {
 #pragma unroll
-            for (int j = k + 1; j < NMAX; ++j) {
-                const double pr = cg_readlane_f64(a[j], p);
-                a[j] = fma(-l, pr, a[j]);
+                for (int m = m0; m < MH; ++m) mine[m] = a[m];
             }
-            done = done || (lane == p);
+            asm volatile("" ::: "memory");            // cross-lane hand-off: the reads below must stay behind the stores
+#pragma unroll
+            for (int m = m0; m < MH; ++m) a[m] = fma(-l, mine[m], a[m]);
+            asm volatile("" ::: "memory");
+            done = done || isp;
         }
     }
     return prod.logabs();
 }
 
-// complex version: A interleaved (re,im) N x N in LDS; returns log|det| and arg(det) including the permutation sign
+// complex version: A interleaved (re,im) N x N in LDS, N <= NMAX <= 16; scr: 32 doubles of LDS.
+// Returns log|det| and arg(det) including the sign of the equivalent row permutation.
 template <int NMAX>
-__device__ __forceinline__ void cg_wave_lu_logdet_complex(const double* A, int N, int lda, double& logabs, double& arg) {
-    const int lane = threadIdx.x & 63;
-    double ar[NMAX], ai[NMAX];
+__device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int N, int lda, double* scr, double& logabs, double& arg) {
+    constexpr int MQ = (NMAX + 3) / 4;
+    const int lane = threadIdx.x & 63, r = lane >> 2, c = lane & 3;
+    double ar[MQ], ai[MQ];
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        const bool ok = lane < N && j < N;
-        ar[j] = ok ? A[2 * (lane * lda + j)] : 0.0;
-        ai[j] = ok ? A[2 * (lane * lda + j) + 1] : 0.0;
+    for (int m = 0; m < MQ; ++m) {
+        const int j = 4 * m + c;
+        const bool ok = r < N && j < N;
+        ar[m] = ok ? A[2 * (r * lda + j)] : 0.0;
+        ai[m] = ok ? A[2 * (r * lda + j) + 1] : 0.0;
     }
-    bool done = lane >= N;
-    int mypos = lane;                 // position of this row under the equivalent sequence of row swaps
+    bool done = r >= N;
+    int mypos = r;                    // position of this row under the equivalent sequence of row swaps
     int parity = 0;
     CgCplx pm = {1.0, 0.0}; int pe = 0;
+    double* mine = scr + 2 * c;       // complex element j = 4 m + c of the published row at scr[2 j]
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
         if (k < N) {
-            const double m2 = ar[k] * ar[k] + ai[k] * ai[k];
+            const int ck = k & 3, mk = k >> 2;
+            double akr, aki;
+            if (ck == 0) { akr = cg_dpp_f64<0x00>(ar[mk]); aki = cg_dpp_f64<0x00>(ai[mk]); }
+            else if (ck == 1) { akr = cg_dpp_f64<0x55>(ar[mk]); aki = cg_dpp_f64<0x55>(ai[mk]); }
+            else if (ck == 2) { akr = cg_dpp_f64<0xAA>(ar[mk]); aki = cg_dpp_f64<0xAA>(ai[mk]); }
+            else { akr = cg_dpp_f64<0xFF>(ar[mk]); aki = cg_dpp_f64<0xFF>(ai[mk]); }
+            const double m2 = akr * akr + aki * aki;
             const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
             const unsigned mx = cg_wave_max_u32(key);
             const unsigned long long mask = __ballot(key == mx && !done);
-            const int p = mask ? (int)__builtin_ctzll(mask) : k;
+            const int p = mask ? (int)__builtin_ctzll(mask) : 4 * k;
+            const bool isp = r == (p >> 2);
             const int posp = __builtin_amdgcn_readlane(mypos, p);
             if (posp != k) {          // swap positions k <-> posp
                 parity ^= 1;
                 if (mypos == k) mypos = posp;
-                if (lane == p) mypos = k;
+                if (isp) mypos = k;
             }
-            const CgCplx piv = {cg_readlane_f64(ar[k], p), cg_readlane_f64(ai[k], p)};
+            const CgCplx piv = {cg_readlane_f64(akr, p), cg_readlane_f64(aki, p)};
             pm = cmul(pm, piv);
-            { int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
-              pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex; }
-            const CgCplx rinv = cinv(piv);
-            CgCplx l = cmul({ar[k], ai[k]}, rinv);
-            if (done || lane == p) { l.re = 0.0; l.im = 0.0; }
-#pragma unroll
-            for (int j = k + 1; j < NMAX; ++j) {
-                const double pr = cg_readlane_f64(ar[j], p), pi = cg_readlane_f64(ai[j], p);
-                ar[j] = fma(-l.re, pr, fma(l.im, pi, ar[j]));
-                ai[j] = fma(-l.re, pi, fma(-l.im, pr, ai[j]));
+            if ((k & 3) == 3) {       // |piv| = O(1..n): four factors cannot overflow between renormalisations
+                int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
+                pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex;
             }
-            done = done || (lane == p);
+            const double rd = cg_fast_rcp(piv.re * piv.re + piv.im * piv.im);
+            const CgCplx rinv = {piv.re * rd, -piv.im * rd};
+            CgCplx l = cmul({akr, aki}, rinv);
+            if (done || isp) { l.re = 0.0; l.im = 0.0; }
+            const int m0 = ck == 3 ? mk + 1 : mk;
+            if (isp) {
+#pragma unroll
+                for (int m = m0; m < MQ; ++m) { mine[8 * m] = ar[m]; mine[8 * m + 1] = ai[m]; }
+            }
+            asm volatile("" ::: "memory");            // cross-lane hand-off through LDS (see the real version)
+#pragma unroll
+            for (int m = m0; m < MQ; ++m) {
+                const double pr = mine[8 * m], pi = mine[8 * m + 1];
+                ar[m] = fma(-l.re, pr, fma(l.im, pi, ar[m]));
+                ai[m] = fma(-l.re, pi, fma(-l.im, pr, ai[m]));
+            }
+            asm volatile("" ::: "memory");
+            done = done || isp;
         }
     }
     if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
