@@ -69,6 +69,29 @@ static __device__ __forceinline__ void cg_stamp_flush() {
 #define CG_STAMP_END(k)
 #endif
 
+// ---- rarely executed libm calls, kept OUT of line on the GPU --------------------------------------------------------
+// log / exp / atan2 / sincos are called a handful of times per log Psi evaluation (LU epilogues, Slater phases, the
+// accept test, Box-Muller).  Inlined, each drags 10-20 fp64 literal constants into the kernel body; the compiler hoists
+// their materialisation out of the Metropolis loop and then spills them (they were most of the scratch traffic).
+// As out-of-line leaf functions the constants live only inside the callee.
+#if defined(__HIPCC__)
+#define CG_OUTLINE __host__ __device__ __attribute__((noinline))
+#else
+#define CG_OUTLINE inline
+#endif
+struct CgSinCos { double s, c; };
+#if defined(__HIPCC__)
+static CG_OUTLINE double cg_log_ool(double x) { return log(x); }
+static CG_OUTLINE double cg_exp_ool(double x) { return exp(x); }
+static CG_OUTLINE double cg_atan2_ool(double y, double x) { return atan2(y, x); }
+static CG_OUTLINE CgSinCos cg_sincos_ool(double a) { CgSinCos r; sincos(a, &r.s, &r.c); return r; }
+#else
+static inline double cg_log_ool(double x) { return log(x); }
+static inline double cg_exp_ool(double x) { return exp(x); }
+static inline double cg_atan2_ool(double y, double x) { return atan2(y, x); }
+static inline CgSinCos cg_sincos_ool(double a) { CgSinCos r; r.s = sin(a); r.c = cos(a); return r; }
+#endif
+
 // ---- fp64 transcendentals specialised for the flow's activations ---------------------------------------------
 // gfx950 has no f64 exp/log instructions.  The generic ocml routines carry range / special-case handling these
 // call sites do not need, and a plain polynomial evaluation costs ~65 VALU instructions per softplus.  The versions
@@ -198,7 +221,7 @@ struct CgScaledProd {
     CG_DEVI void mul(double v) {
         int ex; m = frexp(m * v, &ex); e += ex;
     }
-    CG_DEVI double logabs() const { return log(fabs(m)) + (double)e * 0.693147180559945309417232121458; }
+    CG_DEVI double logabs() const { return cg_log_ool(fabs(m)) + (double)e * 0.693147180559945309417232121458; }
 };
 
 struct CgCplx { double re, im; };

@@ -3,8 +3,19 @@
 // X(D, HS, HT)
 #if defined(CG_ONLY_2_16_16)      /* diagnostic builds: one configuration, a fifth of the compile time */
 #define CG_FAST_CONFIGS(X) X(2, 16, 16)
+#elif defined(CG_ONLY_3_4_4)
+#define CG_FAST_CONFIGS(X) X(3, 4, 4)
 #else
 #define CG_FAST_CONFIGS(X) X(2, 16, 16) X(3, 16, 16) X(2, 4, 4) X(3, 4, 4) X(2, 8, 8) X(3, 8, 8) X(2, 32, 32)
+#endif
+
+// Sampler kernels additionally specialised on the particle number and the workgroup size: X(D, HS, HT, N, THREADS).
+// With n a compile-time constant every LDS offset, trip count and tile count of the chain folds away (the runtime-n
+// kernel keeps ~100 scalar registers of layout state alive across the Metropolis loop and spills them).
+#if defined(CG_NO_SPECIALS) || defined(CG_ONLY_3_4_4)
+#define CG_MCMC_SPECIALS(X)
+#else
+#define CG_MCMC_SPECIALS(X) X(2, 16, 16, 13, 64)
 #endif
 
 static inline bool cg_fast_supported(int depth, int dim, int hs, int ht) {

@@ -99,7 +99,6 @@ struct CgFast {
     struct WFrag {
         const double* th;
         double tw[P + 1];  // two-particle layer column h = lane & 15: bias, then P weights  (pair-primal pass)
-        double gw[P];      // W0 column h = lane & 15                                        (G pass)
     };
     struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
     struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
@@ -117,7 +116,7 @@ struct CgFast {
         w.th = th_in;
         w.tw[0] = th[o_t0b + col];
 #pragma unroll
-        for (int f = 0; f < P; ++f) { w.tw[1 + f] = th[o_t0w + f * HT + col]; w.gw[f] = th[o_W0 + f * HS + col]; }
+        for (int f = 0; f < P; ++f) w.tw[1 + f] = th[o_t0w + f * HT + col];
     }
     static __device__ __forceinline__ void load_dense_p(const double* __restrict__ th_in, DenseP& w) {
         const double* th = th_in;
@@ -225,48 +224,67 @@ struct CgFast {
             if (rowok) { m1[i * HT + h] = acc * rn; if (h < P) m0[i * P + h] = raw * rn; }
         }
     }
-    // G pass with shared pair features (same row layout: row = particle k, lane = hidden unit h)
-    template <int LL>
-    static __device__ __forceinline__ void g_pair_step(const PF6& mine, const WFrag& w, int k, int lbase, int n, int h,
-                                                       double sgk, const double* sg1, double c1, double c2c, double* acc) {
-        if constexpr (LL < 16) {
-            if (lbase + LL < n) {
-                PF6 pf; pf_bcast<LL>(mine, pf);
-                const int l = lbase + LL;
-                const double sgl = sg1[l * HS + h];
-                if (l != k) {
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) {
-                        const double odd = (-c1 * w.gw[bb]) * pf.s2[bb] + (c2c * w.gw[2 * D]) * (pf.s2[bb] * pf.rdel);
-                        const double evn = (c1 * w.gw[D + bb]) * pf.c2[bb];
-                        acc[bb] += sgk * (odd + evn) - sgl * (evn - odd);
-                    }
-                }
-                g_pair_step<LL + 1>(mine, w, k, lbase, n, h, sgk, sg1, c1, c2c, acc);
-            }
-        }
-    }
-    static __device__ __forceinline__ void g_pass_dpp(const CgBlk& b, const WFrag& wfr, int n, double L, double* lds, const CgFastLds& o) {
-        WFrag w; load_pair_cols(wfr.th, w);
+    // G pass on the matrix cores.  With the pair-feature matrices (zero diagonal, b = direction)
+    //     C_b[k][l] = cos(2 pi r_kl,b / L),   S_b[k][l] = sin(2 pi r_kl,b / L),   R_b[k][l] = S_b[k][l] / |sin(pi r_kl / L)|
+    // the sum over l of  sg1_k (odd + evn) - sg1_l (evn - odd)  (see the scalar G pass in jacobian()) becomes
+    //     n^2 G_k[h][b] =   c1 W0s[b][h] ( sg1_k[h] rowsum C_b[k] - (C_b sg1)[k][h] )
+    //                     - c1 W0c[b][h] ( sg1_k[h] rowsum S_b[k] + (S_b sg1)[k][h] )
+    //                     + c2c W0d[h]   ( sg1_k[h] rowsum R_b[k] + (R_b sg1)[k][h] )
+    // i.e. 3 D products (n x n)(n x 16) plus their row sums (the same A operand against a ones B operand).
+    // A operand: lane (row k = l & 15, l' = 4 ks + (l >> 4)) computes the features of ITS pair once -- no 16-fold
+    // redundancy and no DPP broadcast; the pass costs ~4 pair-feature evaluations per lane and tile instead of
+    // n/4 x 13 x ~30 VALU instructions.
+    static __device__ __forceinline__ void g_pass_mfma(const CgBlk& b, const WFrag& wfr, int n, double L, double* lds, const CgFastLds& o) {
+        const double* th = wfr.th;
+        asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
         const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1;
         double* G = lds + o.G;
+        const int l = b.tid & 63, col = l & 15, kq = l >> 4;
+        const int wave = b.tid >> 6, nw = b.nthr >> 6;
+        const int tiles = (n + 15) >> 4;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
-        const int h = b.tid & 15;
-        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {
-            const int k = (e0 + (b.tid & 63)) >> 4;
-            const bool rowok = k < n;
-            const double sgk = rowok ? sg1[k * HS + h] : 0.0;
-            double acc[D];
+        double kc[D], ksn[D];                                         // -c1 W0c[b][h], c1 W0s[b][h] of column h = col
 #pragma unroll
-            for (int a = 0; a < D; ++a) acc[a] = 0.0;
-            for (int lb = 0; lb < n; lb += 16) {
-                PF6 mine; own_pair(sh, ch, rowok ? k : 0, lb + h, rowok && lb + h < n, mine);
-                g_pair_step<0>(mine, w, k, lb, n, h, sgk, sg1, c1, c2c, acc);
+        for (int a = 0; a < D; ++a) { kc[a] = -c1 * th[o_W0 + a * HS + col]; ksn[a] = c1 * th[o_W0 + (D + a) * HS + col]; }
+        const double kd = c2c * th[o_W0 + 2 * D * HS + col];
+        for (int kt = wave; kt < tiles; kt += nw) {
+            const int k = 16 * kt + col;                              // A row of this lane
+            d4_t pC[D], pS[D], pR[D], sC[D], sS[D], sR[D];            // products with sg1 / row sums
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                pC[a] = d4_t{0, 0, 0, 0}; pS[a] = pC[a]; pR[a] = pC[a]; sC[a] = pC[a]; sS[a] = pC[a]; sR[a] = pC[a];
             }
-            if (rowok) {
+            for (int lt = 0; lt < tiles; ++lt) {
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) G[iG(k, h, bb)] = acc[bb] * rn * rn;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int lp = 16 * lt + 4 * ks + kq;             // k-dimension index of this lane
+                    const bool inr = lp < n;
+                    PF6 pf; own_pair(sh, ch, k, lp, k < n && inr, pf);
+                    const double bS = inr ? sg1[lp * HS + col] : 0.0; // B[l'][h]; rows l' >= n contribute nothing
+                    const double bO = inr ? 1.0 : 0.0;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double xC = (lp == k) ? 0.0 : pf.c2[a];  // own_pair's exact diagonal feature is [1, 0, 0]
+                        const double xS = pf.s2[a], xR = pf.s2[a] * pf.rdel;
+                        pC[a] = mfma(xC, bS, pC[a]); sC[a] = mfma(xC, bO, sC[a]);
+                        pS[a] = mfma(xS, bS, pS[a]); sS[a] = mfma(xS, bO, sS[a]);
+                        pR[a] = mfma(xR, bS, pR[a]); sR[a] = mfma(xR, bO, sR[a]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * kt + kq + 4 * r;                  // C/D row of this lane
+                if (kk < n) {
+                    const double sgk = sg1[kk * HS + col];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double v = ksn[a] * fma(sgk, sC[a][r], -pC[a][r]) + kc[a] * fma(sgk, sS[a][r], pS[a][r])
+                                         + kd * fma(sgk, sR[a][r], pR[a][r]);
+                        G[iG(kk, col, a)] = v * rn * rn;
+                    }
+                }
             }
         }
     }
@@ -455,7 +473,7 @@ struct CgFast {
         CG_STAMP(4)
         jac_factors_mfma<0>(b, w, n, lds, o, wfl);
         CG_STAMP(5)
-        g_pass_dpp(b, w, n, L, lds, o);
+        g_pass_mfma(b, w, n, L, lds, o);
         b.sync();
         CG_STAMP(6)
         jac_up_mfma(b, w, n, lds, o);
@@ -785,8 +803,8 @@ struct CgFast {
             double ph = 0.0;
 #pragma unroll
             for (int a = 0; a < D; ++a) ph += k[a] * z[i * D + a];
-            double s, c; sincos(ph, &s, &c);
-            Dm[2 * e] = c; Dm[2 * e + 1] = s;
+            const CgSinCos sc = cg_sincos_ool(ph);
+            Dm[2 * e] = sc.c; Dm[2 * e + 1] = sc.s;
         }
         b.sync();
     }
@@ -850,7 +868,7 @@ struct CgFast {
             cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
         }
 #endif
-        re_phi = la - (double)n * (0.5 * D) * log(L);
+        re_phi = la - (double)n * (0.5 * D) * cg_log_ool(L);
         im_phi = ar;
     }
 };
@@ -863,7 +881,7 @@ struct CgFast {
 //       jacobian        U (dead once Up is formed)                                    -> lives inside J
 //                       V Bm Up G J
 //       Slater matrix   Dm: after the LU of J                                          -> on top of V Bm Up G, or on J
-static inline CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, bool mfma = false) {
+static CG_HD CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, bool mfma = false) {
     CgFastLds o; int P = 2 * D + 1, t = 0;
     auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
     o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);

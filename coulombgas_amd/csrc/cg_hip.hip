@@ -77,18 +77,22 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_l
 
 // Batched Metropolis chain: src/MCMC.py:22-39.  One workgroup owns one walker for all mc_steps;
 // x is read once and written once, the proposal/accept state never leaves the CU.
-template <int D, int HS, int HT, int MAXT>
+// NS > 0: specialised on n = NS and on a workgroup of exactly MAXT threads (CG_MCMC_SPECIALS).
+template <int D, int HS, int HT, int MAXT, int NS = 0>
 __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_mcmc(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, double* __restrict__ x, const int* __restrict__ sidx, int B, int steps, double stddev,
                        uint64_t seed, uint64_t walker_offset, const double* __restrict__ noise,
                        const double* __restrict__ unif, double* __restrict__ logp_out,
                        unsigned long long* __restrict__ n_accept) {
     using F = CgFast<D, HS, HT>;
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
-    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    const CgBlk b{(int)threadIdx.x, NS > 0 ? MAXT : (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     __syncthreads();
-    const int n = m.n, N = n * D;
-    double* xc = lds + m.lay.total;          // current configuration
+    const int n = NS > 0 ? NS : m.n, N = n * D;
+    CgFastLds lay_s = m.lay;
+    if constexpr (NS > 0) lay_s = cg_fast_layout(NS, D, HS, HT, true, HS == 16 && HT == 16);   // folds to constants
+    const CgFastLds& lay = lay_s;
+    double* xc = lds + lay.total;          // current configuration
     double* xp = xc + ((N + 1) & ~1);        // proposal
     int* flag = (int*)(xp + ((N + 1) & ~1));
     CG_STAMP_INIT
@@ -115,13 +119,21 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
             b.sync();
             CG_STAMP(0)
             double re, im, h;
-            F::logpsi(b, theta, xp, spk, si, n, m.L, lds, m.lay, re, im, h, wf);
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CG_NO_OPAQUE_TID)
+            // the lane id is made opaque once per evaluation: everything derived from it (LDS addresses, tile indices)
+            // is then recomputed inside the evaluation instead of being hoisted out of the chain loop and spilled
+            int tid_o = b.tid; asm volatile("" : "+v"(tid_o));
+            const CgBlk be{tid_o, b.nthr};
+#else
+            const CgBlk& be = b;
+#endif
+            F::logpsi(be, theta, xp, spk, si, n, m.L, lds, lay, re, im, h, wf);
             const double lp = 2.0 * (re + h);
             if (b.tid == 0) {
                 int acc = 1;
                 if (s >= 0) {
                     const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
-                    const double ratio = exp(lp - logp);
+                    const double ratio = cg_exp_ool(lp - logp);
                     acc = (u < ratio) ? 1 : 0;            // NaN -> reject, +inf -> accept (src/MCMC.py:28-29)
                 }
                 *flag = acc;
@@ -170,11 +182,15 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 }
 
 // grad / Laplacian of log Psi w.r.t. x (cg_derivs.hpp); per-walker workspace in HBM.
+// Register budget: 3 waves/SIMD (168 VGPRs) for d = 2.  For d = 3 the jets of the d x d blocks need ~480 spilled VGPRs at
+// that budget and the spill-heavy code hipcc (ROCm 7.2) generates returns wrong jets for every direction but the first
+// (deterministic; parity test test_grad_laplacian_all_modes[case1]); at 2 waves/SIMD it is correct and no slower.
 #ifndef CG_DERIV_WAVES
 #define CG_DERIV_WAVES 3
 #endif
+#define CG_DERIV_WAVES_OF(D) ((D) == 2 ? CG_DERIV_WAVES : (CG_DERIV_WAVES < 2 ? CG_DERIV_WAVES : 2))
 template <int D, int HS, int HT>
-__global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+__global__ void __launch_bounds__(256, CG_DERIV_WAVES_OF(D)) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
                            double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
@@ -191,7 +207,7 @@ __global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_grad_lap(CgDev m, const
 }
 
 template <int D, int HS, int HT>
-__global__ void __launch_bounds__(256, CG_DERIV_WAVES) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+__global__ void __launch_bounds__(256, CG_DERIV_WAVES_OF(D)) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
                             const double* __restrict__ w_re, const double* __restrict__ w_im,
                             double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
                             double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
@@ -294,7 +310,7 @@ __global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const
                 int acc = 1;
                 if (s >= 0) {
                     const double u = unif ? unif[(size_t)s * B + q] : cg_philox_uniform(seed, walker_offset + q, (uint32_t)s);
-                    acc = (u < exp(lp - logp)) ? 1 : 0;
+                    acc = (u < cg_exp_ool(lp - logp)) ? 1 : 0;
                 }
                 *flag = acc;
             }
@@ -789,6 +805,16 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
     const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
     const CgDev m = make_dev(c);
     bool launched = false;
+#define CG_X(D, HS, HT, NS, NT)                                                                                     \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT && c->n == NS && nt == NT) {                        \
+        if ((rc = set_lds(c, k_mcmc<D, HS, HT, NT, NS>, lds))) return rc;                                           \
+        hipLaunchKernelGGL((k_mcmc<D, HS, HT, NT, NS>), dim3(B), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (double*)ax.dev,     \
+                           (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,                         \
+                           (const double*)an.dev, (const double*)au.dev, (double*)al.dev, c->d_accept);             \
+        launched = true;                                                                                            \
+    }
+    CG_MCMC_SPECIALS(CG_X)
+#undef CG_X
 #define CG_X(D, HS, HT)                                                                                             \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                  \
         if (nt <= 256) {                                                                                            \

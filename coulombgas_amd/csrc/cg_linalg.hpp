@@ -126,8 +126,8 @@ CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int
         }
         b.sync();
     }
-    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = atan2(pm.im, pm.re);
+    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = cg_atan2_ool(pm.im, pm.re);
 }
 
 // In-place inverse by Gauss-Jordan with partial pivoting on [A | I] -> [I | A^-1].
@@ -233,8 +233,8 @@ CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, doubl
         Ainv[2 * (k * ldi + j)] = A[2 * (k * lda + j)]; Ainv[2 * (k * ldi + j) + 1] = A[2 * (k * lda + j) + 1];
     }
     b.sync();
-    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = atan2(pm.im, pm.re);
+    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = cg_atan2_ool(pm.im, pm.re);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -408,8 +408,8 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
         }
     }
     if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
-    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = atan2(pm.im, pm.re);
+    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = cg_atan2_ool(pm.im, pm.re);
 }
 #endif
 
@@ -485,7 +485,7 @@ __device__ __forceinline__ void cg_wave_lds_lu_logdet_complex(double* A, int N, 
         }
         cg_wave_lds_fence();
     }
-    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = atan2(pm.im, pm.re);
+    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = cg_atan2_ool(pm.im, pm.re);
 }
 #endif

@@ -23,12 +23,24 @@ CG_DEVI void cg_philox_uniform2(uint64_t seed, uint64_t walker, uint32_t step, u
     u_open = ((double)a + 0.5) * (1.0 / 9007199254740992.0);
     u_half = (double)bb * (1.0 / 9007199254740992.0);
 }
-CG_DEVI double cg_philox_normal(uint64_t seed, uint64_t walker, uint32_t step, uint32_t item) {
+// out of line on the GPU (one call per coordinate and Metropolis step): the Philox key schedule and the constants of
+// log / sincos / sqrt stay inside the callee instead of being hoisted out of the chain loop
+#if defined(__HIPCC__)
+static CG_OUTLINE
+#else
+static inline
+#endif
+double cg_philox_normal(uint64_t seed, uint64_t walker, uint32_t step, uint32_t item) {
     double u1, u2; cg_philox_uniform2(seed, walker, step, item, u1, u2);
     double s, c; sincos(2.0 * CG_PI * u2, &s, &c);
     return sqrt(-2.0 * log(u1)) * c;
 }
-CG_DEVI double cg_philox_uniform(uint64_t seed, uint64_t walker, uint32_t step) {
+#if defined(__HIPCC__)
+static CG_OUTLINE
+#else
+static inline
+#endif
+double cg_philox_uniform(uint64_t seed, uint64_t walker, uint32_t step) {
     double u1, u2; cg_philox_uniform2(seed, walker, step, 0xFFFFFFFFu, u1, u2);
     return u2;
 }
