@@ -74,7 +74,12 @@ static __device__ __forceinline__ void cg_stamp_flush() {
 // accept test, Box-Muller).  Inlined, each drags 10-20 fp64 literal constants into the kernel body; the compiler hoists
 // their materialisation out of the Metropolis loop and then spills them (they were most of the scratch traffic).
 // As out-of-line leaf functions the constants live only inside the callee.
-#if defined(__HIPCC__)
+// ONLY the depth-2 sampler kernels (k_logpsi / k_mcmc) call these: inside the spill-heavy derivative kernels hipcc
+// (ROCm 7.2) miscompiled the calls (d = 3 jets: the direction counter was lost across them), so every other path keeps
+// the inlined libm call (`ool` arguments below default to false).
+#if defined(__HIPCC__) && defined(CG_NO_OUTLINE)      /* diagnostic builds */
+#define CG_OUTLINE __host__ __device__ __forceinline__
+#elif defined(__HIPCC__)
 #define CG_OUTLINE __host__ __device__ __attribute__((noinline))
 #else
 #define CG_OUTLINE inline
@@ -182,7 +187,15 @@ CG_DEVI void softplus_sigmoid(double u, double& sp, double& sg) {
 }
 CG_DEVI double sigmoid_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));
-    double lg, r; cg_log_rcp_12(1.0 + e, lg, r);
+    const double w = 1.0 + e;                             // in [1, 2]
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 1/w from v_rcp_f64 + two Newton steps (no table look-up, no w = 2 special case): 5 instructions instead of 15
+    double r = __builtin_amdgcn_rcp(w);
+    r = fma(r, fma(-w, r, 1.0), r);
+    r = fma(r, fma(-w, r, 1.0), r);
+#else
+    const double r = 1.0 / w;
+#endif
     return (u >= 0.0) ? r : e * r;
 }
 // log(w) only, w in [1, 2]  (same table as cg_log_rcp_12, without the reciprocal)
@@ -221,7 +234,9 @@ struct CgScaledProd {
     CG_DEVI void mul(double v) {
         int ex; m = frexp(m * v, &ex); e += ex;
     }
-    CG_DEVI double logabs() const { return cg_log_ool(fabs(m)) + (double)e * 0.693147180559945309417232121458; }
+    CG_DEVI double logabs(bool ool = false) const {
+        return (ool ? cg_log_ool(fabs(m)) : log(fabs(m))) + (double)e * 0.693147180559945309417232121458;
+    }
 };
 
 struct CgCplx { double re, im; };

@@ -224,6 +224,85 @@ struct CgFast {
             if (rowok) { m1[i * HT + h] = acc * rn; if (h < P) m0[i * P + h] = raw * rn; }
         }
     }
+    // Pair-primal pass, features handed off through LDS.  Same work split as primal_pairs_dpp (a 16-lane row owns particle
+    // i, lane h = hidden unit; each lane computes the features of ONE pair (i, 16 c + h)), but the row then walks j by
+    // reading pair (i, j) back from an LDS scratch (broadcast reads: no VALU issue slots) instead of 10 v_mov_dpp per
+    // step.  The scratch is J's slot, dead until the Jacobian assembly.  The means of the cos / sin features are taken
+    // from their closed form  sum_j cos(t_i - t_j) = cos t_i C + sin t_i S,  sum_j sin(t_i - t_j) = sin t_i C - cos t_i S
+    // (t = 2 pi x / L, C = sum_j cos t_j, S = sum_j sin t_j; the diagonal feature [1, 0] is the j = i term), so only the
+    // norm feature is accumulated in the pair loop.
+    static constexpr int PFS = 2 * D + 2;                  // doubles per pair in the scratch: c2[D], s2[D], del, pad
+    static constexpr int PFROW = 16 * PFS + 2;             // row stride (padded against bank conflicts between the 4 rows)
+    static constexpr int PFWAVE = 4 * PFROW + 2 * D + 2;   // per wave: 4 rows + C[D], S[D]
+    static __device__ __forceinline__ bool primal_pairs_lds_fits(const CgBlk& b, int n) {
+        return (b.nthr >> 6) * PFWAVE <= n * D * n * D;
+    }
+    static __device__ __forceinline__ void primal_pairs_lds(const CgBlk& b, const WFrag& wfr, int n, double* lds, const CgFastLds& o) {
+        WFrag w; load_pair_cols(wfr.th, w);
+        const double *sh = lds + o.sh, *ch = lds + o.ch;
+        double *m0 = lds + o.m0, *m1 = lds + o.m1;
+        const double rn = 1.0 / (double)n;
+        const int lane = b.tid & 63, h = lane & 15, rr = lane >> 4;
+        double* scr = lds + o.J + (b.tid >> 6) * PFWAVE;   // this wave's scratch
+        double* cs = scr + 4 * PFROW;                      // C[a] at cs[a], S[a] at cs[D + a]
+        if (lane < 2 * D) {
+            const int a = lane < D ? lane : lane - D;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double sj = sh[j * D + a], cj = ch[j * D + a];
+                acc += lane < D ? 1.0 - 2.0 * (sj * sj) : 2.0 * (sj * cj);
+            }
+            cs[lane] = acc;
+        }
+        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {      // whole waves stay together
+            const int i = (e0 + lane) >> 4;
+            const bool rowok = i < n;
+            double acc = 0.0, rawd = 0.0;
+            for (int jb = 0; jb < n; jb += 16) {
+                PF6 mine; own_pair(sh, ch, rowok ? i : 0, jb + h, rowok && jb + h < n, mine);
+                double* slot = scr + rr * PFROW + h * PFS;
+#pragma unroll
+                for (int a = 0; a < D; ++a) { slot[a] = mine.c2[a]; slot[D + a] = mine.s2[a]; }
+                slot[2 * D] = mine.del;
+                asm volatile("" ::: "memory");             // cross-lane hand-off (LDS executes one wave's accesses in order)
+                const int jn = n - jb < 16 ? n - jb : 16;
+                const double* row = scr + rr * PFROW;
+                // two independent softplus chains per trip: each has three LDS round trips (features, exp table, log
+                // table) on its critical path, and one wave alone cannot hide them behind a single chain
+                auto uof = [&](const double* pf) {
+                    double u = w.tw[0] + w.tw[1 + 2 * D] * pf[2 * D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) u += w.tw[1 + a] * pf[a] + w.tw[1 + D + a] * pf[D + a];
+                    return u;
+                };
+                int jj = 0;
+                for (; jj + 1 < jn; jj += 2) {
+                    const double* pa = row + jj * PFS; const double* pb = pa + PFS;
+                    const double ua = uof(pa), ub = uof(pb);
+                    rawd += pa[2 * D] + pb[2 * D];
+                    acc += softplus_only(ua) + softplus_only(ub);
+                }
+                if (jj < jn) {
+                    const double* pa = row + jj * PFS;
+                    rawd += pa[2 * D];
+                    acc += softplus_only(uof(pa));
+                }
+                asm volatile("" ::: "memory");             // the next block's stores stay behind these reads
+            }
+            if (rowok) {
+                m1[i * HT + h] = acc * rn;
+                if (h < 2 * D) {
+                    const int a = h < D ? h : h - D;
+                    const double si = sh[i * D + a], ci = ch[i * D + a];
+                    const double ct = 1.0 - 2.0 * (si * si), st = 2.0 * (si * ci);
+                    m0[i * P + h] = (h < D ? ct * cs[a] + st * cs[D + a] : st * cs[a] - ct * cs[D + a]) * rn;
+                } else if (h == 2 * D) {
+                    m0[i * P + h] = rawd * rn;
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
     // G pass on the matrix cores.  With the pair-feature matrices (zero diagonal, b = direction)
     //     C_b[k][l] = cos(2 pi r_kl,b / L),   S_b[k][l] = sin(2 pi r_kl,b / L),   R_b[k][l] = S_b[k][l] / |sin(pi r_kl / L)|
     // the sum over l of  sg1_k (odd + evn) - sg1_l (evn - odd)  (see the scalar G pass in jacobian()) becomes
@@ -550,7 +629,7 @@ struct CgFast {
                *z = lds + o.z;
         const double rn = 1.0 / (double)n;
         for (int e = b.tid; e < n * D; e += b.nthr) {
-            T s, c; cg_sincos(x[e] * (CG_PI / L), s, c);
+            T s, c; cg_sincos(x[e] * (CG_PI / L), s, c, wf != nullptr);    // out of line in the sampler kernels only
             sh[e] = s; ch[e] = c;
         }
         b.sync();
@@ -558,7 +637,11 @@ struct CgFast {
         bool pairs_done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
-            if (wf) { primal_pairs_dpp(b, *wf, n, (double*)lds, o); pairs_done = true; }
+            if (wf) {
+                if (primal_pairs_lds_fits(b, n)) primal_pairs_lds(b, *wf, n, (double*)lds, o);
+                else primal_pairs_dpp(b, *wf, n, (double*)lds, o);
+                pairs_done = true;
+            }
         }
 #endif
         // pair-primal: item (i,h)
@@ -796,15 +879,15 @@ struct CgFast {
     // k_j = 2 pi / L * sp_indices[state_idx[j]]    (src/slater.py:14-17, src/logpsi.py:23)
     // ---------------------------------------------------------------------------------------
     static CG_DEVI void slater_matrix(const CgBlk& b, const double* z, const double* __restrict__ spk /*M x D, already * 2pi/L*/,
-                                      const int* __restrict__ sidx, int n, double* Dm) {
+                                      const int* __restrict__ sidx, int n, double* Dm, bool ool = false) {
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, j = e - i * n;
             const double* k = spk + (size_t)sidx[j] * D;
             double ph = 0.0;
 #pragma unroll
             for (int a = 0; a < D; ++a) ph += k[a] * z[i * D + a];
-            const CgSinCos sc = cg_sincos_ool(ph);
-            Dm[2 * e] = sc.c; Dm[2 * e + 1] = sc.s;
+            double sn, cs; cg_sincos(ph, sn, cs, ool);
+            Dm[2 * e] = cs; Dm[2 * e + 1] = sn;
         }
         b.sync();
     }
@@ -823,7 +906,7 @@ struct CgFast {
         if (o.wave_lu) {
             // Slater matrix first (its slot does not overlap J), then the two LUs run barrier-free in registers:
             // wave 0 the real Jacobian, wave 1 (if the workgroup has one) the complex Slater matrix, concurrently.
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
             CG_STAMP(12)
             double* res = (double*)perm;
             const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
@@ -847,7 +930,7 @@ struct CgFast {
             CG_STAMP(14)
         } else if (o.Dm != o.J) {
             // mid sizes: single-wave LDS LUs, real on wave 0 and complex on wave 1 concurrently
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
             double* res = (double*)perm;
             const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
             if (wave == 0) { const double v = cg_wave_lds_lu_logabsdet(lds + o.J, n * D, n * D); if (b.tid == 0) res[0] = v; }
@@ -857,15 +940,15 @@ struct CgFast {
             b.sync();
         } else {
             // largest sizes (Slater matrix shares J's LDS): the whole workgroup, one determinant after the other
-            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
-            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm, nullptr, true);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
+            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar, true);
         }
 #else
         {
-            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm);
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm);
-            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar);
+            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm, nullptr, true);
+            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
+            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar, true);
         }
 #endif
         re_phi = la - (double)n * (0.5 * D) * cg_log_ool(L);

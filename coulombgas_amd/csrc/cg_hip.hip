@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
             for (int e = b.tid; e < N; e += b.nthr) {
                 double g = 0.0;
                 if (s >= 0) g = noise ? noise[((size_t)s * B + w) * N + e]
-                                      : cg_philox_normal(seed, walker_offset + w, (uint32_t)s, (uint32_t)e);
+                                      : cg_philox_normal_ool(seed, walker_offset + w, (uint32_t)s, (uint32_t)e);
                 xp[e] = xc[e] + stddev * g;
             }
             b.sync();
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(MAXT, (MAXT <= 256 ? CG_WAVES_PER_EU : 1)) k_m
             if (b.tid == 0) {
                 int acc = 1;
                 if (s >= 0) {
-                    const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform(seed, walker_offset + w, (uint32_t)s);
+                    const double u = unif ? unif[(size_t)s * B + w] : cg_philox_uniform_ool(seed, walker_offset + w, (uint32_t)s);
                     const double ratio = cg_exp_ool(lp - logp);
                     acc = (u < ratio) ? 1 : 0;            // NaN -> reject, +inf -> accept (src/MCMC.py:28-29)
                 }
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const
                 int acc = 1;
                 if (s >= 0) {
                     const double u = unif ? unif[(size_t)s * B + q] : cg_philox_uniform(seed, walker_offset + q, (uint32_t)s);
-                    acc = (u < cg_exp_ool(lp - logp)) ? 1 : 0;
+                    acc = (u < exp(lp - logp)) ? 1 : 0;
                 }
                 *flag = acc;
             }

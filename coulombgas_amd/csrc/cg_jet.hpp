@@ -28,9 +28,12 @@ CG_DEVI Jet2& operator-=(Jet2& a, Jet2 b) { a.v -= b.v; a.d -= b.d; a.dd -= b.dd
 CG_DEVI Jet2 jet_chain(Jet2 u, double f, double f1, double f2) { return {f, f1 * u.d, f1 * u.dd + f2 * u.d * u.d}; }
 
 // --- scalar-generic math used by the templated flow code (T = double or Jet2) ---
-CG_DEVI void cg_sincos(double a, double& s, double& c) { const CgSinCos r = cg_sincos_ool(a); s = r.s; c = r.c; }
-CG_DEVI void cg_sincos(Jet2 a, Jet2& s, Jet2& c) {
-    const CgSinCos r = cg_sincos_ool(a.v); const double sv = r.s, cv = r.c;
+CG_DEVI void cg_sincos(double a, double& s, double& c, bool ool = false) {
+    if (ool) { const CgSinCos r = cg_sincos_ool(a); s = r.s; c = r.c; }
+    else sincos(a, &s, &c);
+}
+CG_DEVI void cg_sincos(Jet2 a, Jet2& s, Jet2& c, bool = false) {
+    double sv, cv; sincos(a.v, &sv, &cv);
     s = jet_chain(a, sv, cv, -sv); c = jet_chain(a, cv, -sv, -cv);
 }
 CG_DEVI double cg_sqrt(double a) { return sqrt(a); }

@@ -48,7 +48,7 @@ CG_DEVI int cg_block_argmax(const CgBlk& b, double v, int idx, double* scratch) 
 // shares).  A is destroyed.  scratch: >= 40 doubles.  getrf-style partial pivoting with physical row swaps; the
 // pivot search is one candidate per thread + a shuffle/LDS argmax (a few hundred cycles per column instead of a
 // serial scan).  Returns the value in every thread.
-CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* scratch_i, int* sign_out = nullptr) {
+CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* scratch_i, int* sign_out = nullptr, bool ool = false) {
     double* scratch = (double*)scratch_i;
     const int TX = b.nthr < 16 ? b.nthr : 16;
     const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
@@ -78,13 +78,13 @@ CG_DEVI double cg_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, int* s
         b.sync();
     }
     if (sign_out) *sign_out = sgn;
-    return prod.logabs();
+    return prod.logabs(ool);
 }
 
 // Complex N x N (interleaved re,im; row-major, lda in complex elements) log det:
 // returns log|det| and arg(det) in (-pi, pi]  (jnp.linalg.slogdet + jnp.log(phase), src/slater.py:18-19)
 CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int* scratch_i,
-                                  double& logabs, double& arg) {
+                                  double& logabs, double& arg, bool ool = false) {
     double* scratch = (double*)scratch_i;
     const int TX = b.nthr < 16 ? b.nthr : 16;
     const int tx = b.tid % TX, ty = b.tid / TX, TY = b.nthr / TX;
@@ -126,8 +126,9 @@ CG_DEVI void cg_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, int
         }
         b.sync();
     }
-    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = cg_atan2_ool(pm.im, pm.re);
+    const double m2 = pm.re * pm.re + pm.im * pm.im;
+    logabs = 0.5 * (ool ? cg_log_ool(m2) : log(m2)) + (double)pe * 0.693147180559945309417232121458;
+    arg = ool ? cg_atan2_ool(pm.im, pm.re) : atan2(pm.im, pm.re);
 }
 
 // In-place inverse by Gauss-Jordan with partial pivoting on [A | I] -> [I | A^-1].
@@ -233,8 +234,8 @@ CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, doubl
         Ainv[2 * (k * ldi + j)] = A[2 * (k * lda + j)]; Ainv[2 * (k * ldi + j) + 1] = A[2 * (k * lda + j) + 1];
     }
     b.sync();
-    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
-    arg = cg_atan2_ool(pm.im, pm.re);
+    logabs = 0.5 * log(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg = atan2(pm.im, pm.re);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -281,6 +282,12 @@ __device__ __forceinline__ double cg_fast_rcp(double x) {
     r = fma(r, e, r);
     return fabs(x) > 0.0 ? r : r0;
 }
+// 1/x with ONE Newton step (~1e-14 relative): enough for LU multipliers (the determinant uses the pivots themselves)
+__device__ __forceinline__ double cg_fast_rcp1(double x) {
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double r = fma(r0, fma(-x, r0, 1.0), r0);
+    return fabs(x) > 0.0 ? r : r0;
+}
 // sqrt(x) and 1/sqrt(x) for x > 0 (normal range) from v_rsq_f64 + two Newton steps
 __device__ __forceinline__ void cg_fast_sqrt_rsqrt(double x, double& sq, double& rs) {
     double y = __builtin_amdgcn_rsq(x);
@@ -310,6 +317,7 @@ __device__ __forceinline__ double cg_wave_lu2_logabsdet(const double* A, int N, 
 #pragma unroll
     for (int m = 0; m < MH; ++m) { const int j = 2 * m + c; a[m] = (r < N && j < N) ? A[r * lda + j] : 0.0; }
     bool done = r >= N;
+    unsigned long long donemask = N >= 32 ? 0ull : ~0ull << (2 * N);          // wave-uniform copy of `done`
     double* mine = scr + c * MHP;
     CgScaledProd prod; prod.init();
 #pragma unroll
@@ -317,13 +325,20 @@ __device__ __forceinline__ double cg_wave_lu2_logabsdet(const double* A, int N, 
         if (k < N) {
             const int ck = k & 1, mk = k >> 1;
             const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);      // column k of this lane's row
-            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(ak)) >> 32) + 1u;
-            const unsigned mx = cg_wave_max_u32(key);
-            const unsigned long long mask = __ballot(key == mx && !done);
-            const int p = mask ? (int)__builtin_ctzll(mask) : 2 * k;     // singular column: any row (pivot 0 -> -inf)
-            const double piv = cg_readlane_f64(ak, p);
+            // threshold pivoting: the first unfinished row serves unless some candidate is more than 4x larger
+            // (growth bounded by 4 per step); only then the full search runs.  The common case (J = I + small) never
+            // leaves the short path, which takes ~30 dependent instructions out of every step.
+            int p = (int)__builtin_ctzll(~donemask);
+            double piv = cg_readlane_f64(ak, p);
+            if (__ballot(!done && fabs(ak) * 0.25 > fabs(piv))) {
+                const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(ak)) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !done);
+                p = mask ? (int)__builtin_ctzll(mask) : p;
+                piv = cg_readlane_f64(ak, p);
+            }
             prod.mul(piv);
-            const double rinv = cg_fast_rcp(piv);
+            const double rinv = cg_fast_rcp1(piv);
             const bool isp = r == (p >> 1);
             const double l = (done || isp) ? 0.0 : ak * rinv;
             const int m0 = ck ? mk + 1 : mk;          // first local column that still lies right of column k (or is k itself)
@@ -336,9 +351,10 @@ __device__ __forceinline__ double cg_wave_lu2_logabsdet(const double* A, int N, 
             for (int m = m0; m < MH; ++m) a[m] = fma(-l, mine[m], a[m]);
             asm volatile("" ::: "memory");
             done = done || isp;
+            donemask |= 3ull << (p & ~1);
         }
     }
-    return prod.logabs();
+    return prod.logabs(true);
 }
 
 // complex version: A interleaved (re,im) N x N in LDS, N <= NMAX <= 16; scr: 32 doubles of LDS.
@@ -356,6 +372,7 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
         ai[m] = ok ? A[2 * (r * lda + j) + 1] : 0.0;
     }
     bool done = r >= N;
+    unsigned long long donemask = N >= 16 ? 0ull : ~0ull << (4 * N);          // wave-uniform copy of `done`
     int mypos = r;                    // position of this row under the equivalent sequence of row swaps
     int parity = 0;
     CgCplx pm = {1.0, 0.0}; int pe = 0;
@@ -370,10 +387,14 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
             else if (ck == 2) { akr = cg_dpp_f64<0xAA>(ar[mk]); aki = cg_dpp_f64<0xAA>(ai[mk]); }
             else { akr = cg_dpp_f64<0xFF>(ar[mk]); aki = cg_dpp_f64<0xFF>(ai[mk]); }
             const double m2 = akr * akr + aki * aki;
-            const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
-            const unsigned mx = cg_wave_max_u32(key);
-            const unsigned long long mask = __ballot(key == mx && !done);
-            const int p = mask ? (int)__builtin_ctzll(mask) : 4 * k;
+            // threshold pivoting (see the real version): first unfinished row unless a candidate is > 4x larger in modulus
+            int p = (int)__builtin_ctzll(~donemask);
+            if (__ballot(!done && m2 * 0.0625 > cg_readlane_f64(m2, p))) {
+                const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !done);
+                p = mask ? (int)__builtin_ctzll(mask) : p;
+            }
             const bool isp = r == (p >> 2);
             const int posp = __builtin_amdgcn_readlane(mypos, p);
             if (posp != k) {          // swap positions k <-> posp
@@ -387,7 +408,7 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
                 int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
                 pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex;
             }
-            const double rd = cg_fast_rcp(piv.re * piv.re + piv.im * piv.im);
+            const double rd = cg_fast_rcp1(piv.re * piv.re + piv.im * piv.im);
             const CgCplx rinv = {piv.re * rd, -piv.im * rd};
             CgCplx l = cmul({akr, aki}, rinv);
             if (done || isp) { l.re = 0.0; l.im = 0.0; }
@@ -405,6 +426,7 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
             }
             asm volatile("" ::: "memory");
             done = done || isp;
+            donemask |= 15ull << (p & ~3);
         }
     }
     if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
@@ -446,7 +468,7 @@ __device__ __forceinline__ double cg_wave_lds_lu_logabsdet(double* A, int N, int
         }
         cg_wave_lds_fence();
     }
-    return prod.logabs();
+    return prod.logabs(true);
 }
 
 __device__ __forceinline__ void cg_wave_lds_lu_logdet_complex(double* A, int N, int lda, double& logabs, double& arg) {

@@ -23,24 +23,23 @@ CG_DEVI void cg_philox_uniform2(uint64_t seed, uint64_t walker, uint32_t step, u
     u_open = ((double)a + 0.5) * (1.0 / 9007199254740992.0);
     u_half = (double)bb * (1.0 / 9007199254740992.0);
 }
-// out of line on the GPU (one call per coordinate and Metropolis step): the Philox key schedule and the constants of
-// log / sincos / sqrt stay inside the callee instead of being hoisted out of the chain loop
-#if defined(__HIPCC__)
-static CG_OUTLINE
-#else
-static inline
-#endif
-double cg_philox_normal(uint64_t seed, uint64_t walker, uint32_t step, uint32_t item) {
+CG_DEVI double cg_philox_normal(uint64_t seed, uint64_t walker, uint32_t step, uint32_t item) {
     double u1, u2; cg_philox_uniform2(seed, walker, step, item, u1, u2);
     double s, c; sincos(2.0 * CG_PI * u2, &s, &c);
     return sqrt(-2.0 * log(u1)) * c;
 }
-#if defined(__HIPCC__)
-static CG_OUTLINE
-#else
-static inline
-#endif
-double cg_philox_uniform(uint64_t seed, uint64_t walker, uint32_t step) {
+CG_DEVI double cg_philox_uniform(uint64_t seed, uint64_t walker, uint32_t step) {
     double u1, u2; cg_philox_uniform2(seed, walker, step, 0xFFFFFFFFu, u1, u2);
     return u2;
 }
+// Out-of-line versions for the depth-2 sampler kernel (one call per coordinate and Metropolis step): the Philox key
+// schedule and the constants of log / sincos / sqrt stay inside the callee instead of being hoisted out of the chain
+// loop and spilled (see CG_OUTLINE in cg_common.hpp for why only that kernel uses them).
+#if defined(__HIPCC__)
+static CG_OUTLINE double cg_philox_normal_ool(uint64_t seed, uint64_t walker, uint32_t step, uint32_t item) {
+    return cg_philox_normal(seed, walker, step, item);
+}
+static CG_OUTLINE double cg_philox_uniform_ool(uint64_t seed, uint64_t walker, uint32_t step) {
+    return cg_philox_uniform(seed, walker, step);
+}
+#endif
