@@ -72,6 +72,32 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=12.0)
             "sample": "%d walkers x %d mc_steps of the same workload (n=%d), %.1f s, OpenMP over walkers" % (Bs2, mc_steps, n, t2)}
 
 
+def energy_check(eng, n, dim, L, sp, theta, sidx, x, rs=10.0, kappa=10, Gmax=15, sample=2):
+    """BASELINE.json's second half of the metric: relative error of <E_loc> (src/VMC.py:38-41, exact Laplacian) of the
+    HIP path vs the CPU restatement (oracle/cg_ref.py, torch.func) on identical inputs: a bounded sample of the walkers
+    the timed chains ended on.  The oracle is used here as the checker only."""
+    import torch
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    t0 = time.perf_counter()
+    xs = np.ascontiguousarray(x[:sample]); ss = np.ascontiguousarray(sidx[:sample])
+    G = cg.kpoints(dim, Gmax)
+    Vconst = n * rs / L * cg.Madelung(dim, kappa, G)
+    eng.set_ewald(kappa, G, rs)
+    g, lap = eng.grad_laplacian(xs, ss, 0, None)
+    E = -lap - (g ** 2).sum(axis=(-2, -1)) + eng.ewald(xs) + Vconst
+    rflow = R.FermiNet(2, 16, 16, L)
+    rparams = R.flow_unravel(R.T(theta), 2, 16, 16, dim)
+    _, rfn = R.make_logpsi_grad_laplacian(R.make_logpsi(rflow, sp, L))
+    gr, lr = rfn(R.T(xs), rparams, torch.as_tensor(ss.astype(np.int64)), None)
+    Er = (-lr - (gr ** 2).sum(dim=(-2, -1))).numpy() + R.potential_energy(R.T(xs), kappa, G, L, rs).numpy() + Vconst
+    return {"E_mean_gpu": float(E.real.mean()), "E_mean_cpu": float(Er.real.mean()),
+            "rel_err_mean": float(abs(E.real.mean() - Er.real.mean()) / abs(Er.real.mean())),
+            "rel_err_max_per_walker": float(np.abs(E - Er).max() / np.abs(Er).max()),
+            "walkers": int(sample), "seconds": time.perf_counter() - t0,
+            "what": "E_loc = -lap - sum grad^2 + Ewald + Vconst, exact Laplacian, rs=%.1f kappa=%d Gmax=%d; HIP path vs oracle/cg_ref.py" % (rs, kappa, Gmax)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +190,7 @@ def main():
     # sanity of the timed state: finite log-probabilities (a NaN chain would still "run fast")
     lp = d_lp.download()
     ok = bool(np.isfinite(lp).all())
+    x_final = d_x.download()
 
     if rank == 0:
         walker_steps = float(B) * args.mc_steps * args.steps * world
@@ -191,9 +218,14 @@ def main():
                     "hbm": {"achieved": (by * B * args.mc_steps / k_avg_s / 1e9) if by else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": (by * B * args.mc_steps / k_avg_s / 1e9 / HBM_PEAK_GBS) if by else None}}
         cpu = None
+        energy = None
         if world == 1 and not args.no_cpu_baseline:
             _, _, _, sidx0, x0 = synthetic(n, dim, B, args.Emax, 0)
             cpu = cpu_baseline(n, dim, L, sp, theta, sidx0, x0, args.mc_steps, args.mc_stddev)
+            try:
+                energy = energy_check(eng, n, dim, L, sp, theta, sidx, x_final, sample=2 if n <= 16 else 1)
+            except Exception as e:             # the checker must never take the timing line down
+                energy = {"error": repr(e)}
         out = {"metric": "walker-steps/sec (batch x mcsteps/s), n=%d 2D batch %d" % (n, B), "value": value,
                "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -202,7 +234,8 @@ def main():
                                       "(MCMC chain incl. flow+Jacobian+Slater logp), in-kernel Philox RNG" % (n, args.Emax, B, args.mc_steps, args.mc_stddev),
                           "walkers_per_gpu": B, "mc_steps": args.mc_steps, "threads_per_walker": eng.launch_info()["threads"],
                           "lds_bytes_per_walker": eng.launch_info()["lds_bytes"]},
-               "accept_rate": accept, "finite": ok, "comm": comm_kind, "roofline": roofline, "cpu_baseline": cpu}
+               "accept_rate": accept, "finite": ok, "comm": comm_kind, "roofline": roofline, "cpu_baseline": cpu,
+               "energy": energy}
         print(json.dumps(out), flush=True)
     if dist is not None:
         comm.close()

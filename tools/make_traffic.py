@@ -14,9 +14,8 @@ write, nw = mean_counter(sys.argv[2], "WRITE_SIZE")
 out = {"kernel": "k_mcmc", "n": int(sys.argv[4]), "batch": int(sys.argv[5]), "mc_steps": int(sys.argv[6]),
        "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "launches_averaged": [nf, nw],
        "bytes_per_launch": (fetch + write) * 1024.0,
-       "note": "FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes; the gfx950 x2 FETCH_SIZE correction of the guide applies to "
-               "16-B-per-lane streaming reads only; this kernel's memory-side traffic is register-spill scratch (4-8 B per lane) "
-               "and L2 refills of the 10 KB of tables, so the figure is reported uncorrected (uncalibrated pattern: true bytes are between "
-               "1x and 2x of the fetch part)"}
+       "note": "FETCH_SIZE/WRITE_SIZE (KB) from separate rocprofv3 --pmc passes, reported uncorrected: the kernel reads x, state_idx and "
+               "8.6 KB of flow parameters and writes x, logp once per CHAIN (no register-spill scratch any more), so the bytes are "
+               "the walker arrays themselves: (2*8*n*d + 4*n + 8) bytes per walker = 3.9 MB at n=13, B=8192, plus table refills"}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(out)
