@@ -325,6 +325,27 @@ __global__ void __launch_bounds__(256) k_gen_mcmc(CgGenModel m, CgGenWs w, const
     }
 }
 
+__global__ void __launch_bounds__(256) k_gen_param_vjp(CgGenModel m, CgGenWs w, const double* __restrict__ theta,
+                                                       const double* __restrict__ spk, const double* __restrict__ tab,
+                                                       const double* __restrict__ x, const int* __restrict__ sidx, int B,
+                                                       const double* __restrict__ w_re, const double* __restrict__ w_im,
+                                                       double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
+                                                       double* wsall) {
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    double* ws = wsall + (size_t)blockIdx.x * w.total;
+    const int n = m.n, N = n * m.dim, P = m.nparam;
+    double* gacc = partial ? partial + (size_t)blockIdx.x * P : nullptr;
+    if (gacc) for (int e = b.tid; e < P; e += b.nthr) gacc[e] = 0.0;
+    b.sync();
+    for (int q = blockIdx.x; q < B; q += gridDim.x) {
+        CgGenK::param_vjp(b, m, w, theta, spk, sidx + (size_t)q * n, x + (size_t)q * N, w_re ? w_re[q] : 1.0, w_im ? w_im[q] : 0.0,
+                          gacc, score ? score + (size_t)q * P * 2 : nullptr, ws);
+        b.sync();
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gen_grad_lap(CgGenModel m, CgGenWs w, const double* __restrict__ theta,
                                                       const double* __restrict__ spk, const double* __restrict__ tab,
                                                       const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
@@ -400,6 +421,7 @@ struct cg_ctx {
     CgFastLds lay;
     CgGenModel gm;               // general-depth path (fast == false)
     CgGenWs gw;
+    CgGenWs gwv;      // the same + the reverse-pass arena of the theta-VJP
     unsigned long long* d_accept = nullptr;
     // staging arena for host-pointer mode + internal workspaces
     std::vector<Chunk> chunks;
@@ -518,6 +540,7 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
     c->fast = fast_ok;
     cg_gen_model_init(c->gm, n, dim, depth, spsize, tpsize, L);
     c->gw = cg_gen_ws(c->gm);
+    c->gwv = cg_gen_ws(c->gm, true);
     c->P = c->gm.nparam;
     memset(&c->lay, 0, sizeof(c->lay));
     if (fast_ok) {
@@ -941,8 +964,6 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
                    const double* w_im, double* g_theta, double* score) {
     int rc = check_ready(c, fn, B); if (rc) return rc;
-    if (!c->fast) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: theta-gradients are implemented for the depth-2 fast path only "
-                          "(depth=%d spsize=%d tpsize=%d runs on the general path)", fn, c->depth, c->hs, c->ht);
     const int n = c->n, N = n * c->dim, P = c->P;
     if (B == 0) {
         if (g_theta && c->ptr_mode == CG_PTR_HOST) memset(g_theta, 0, sizeof(double) * P);
@@ -965,6 +986,13 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
     const CgDev m = make_dev(c);
     bool launched = false;
+    if (!c->fast) {       // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
+        if ((rc = ensure_ws(c, sizeof(double) * c->gwv.total * grid))) return rc;
+        hipLaunchKernelGGL(k_gen_param_vjp, dim3(grid), dim3(256), sizeof(double) * (CG_TAB_DOUBLES + 8), c->stream, c->gm, c->gwv,
+                           (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev,
+                           (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial, (double*)asc.dev, (double*)c->ws);
+        launched = true;
+    }
 #define CG_X(D, HS, HT)                                                                                               \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \

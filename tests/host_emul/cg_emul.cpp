@@ -169,3 +169,18 @@ extern "C" int emu_gen_grad_laplacian(int n, int dim, int depth, int hs, int ht,
                                grad + (size_t)q * N * 2, lap + 2 * q, ws.data(), lds.data());
     return 0;
 }
+
+extern "C" int emu_gen_param_vjp(int n, int dim, int depth, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                                 const int* sidx, const double* x, int B, const double* w_re, const double* w_im, double* g_theta /*+=*/,
+                                 double* score /* B x P x 2, nullable */) {
+    CgGenModel m; cg_gen_model_init(m, n, dim, depth, hs, ht, L);
+    CgGenWs w = cg_gen_ws(m, true);
+    std::vector<double> ws(w.total + 8), spk((size_t)M * dim);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    const int N = n * dim;
+    for (int q = 0; q < B; ++q)
+        CgGenK::param_vjp(b, m, w, theta, spk.data(), sidx + (size_t)q * n, x + (size_t)q * N, w_re ? w_re[q] : 1.0, w_im ? w_im[q] : 0.0,
+                          g_theta, score ? score + (size_t)q * m.nparam * 2 : nullptr, ws.data());
+    return m.nparam;
+}

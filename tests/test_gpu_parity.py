@@ -387,6 +387,18 @@ def test_general_depth_against_oracle(n, dim, depth, hs, ht, L):
     r_logp = R.make_logp(r_logpsi)
     xr, _, rate_r = R.mcmc(lambda xx: r_logp(xx, rparams, sb), R.T(x), R.T(noise), R.T(unif), steps, 0.1)
     assert rate == pytest.approx(rate_r, abs=1e-15) and np.abs(x_new - xr.numpy()).max() < 1e-12
-    from coulombgas_amd._lib import CoulombGasError
-    with pytest.raises(CoulombGasError):
-        flow.engine(n, dim, sp).param_vjp(x, sidx, np.ones(B), np.zeros(B))     # theta-gradients: depth-2 fast path only
+    # theta-VJP and per-sample scores of the general path (dual-number reverse passes, cg_generic.hpp) vs jacrev of the oracle
+    if n <= 7:
+        w_re, w_im = rng.standard_normal(B), rng.standard_normal(B)
+        eng = flow.engine(n, dim, sp); eng.set_params(theta)
+        g = eng.param_vjp(x, sidx, w_re, w_im)
+        lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, depth, hs, ht, dim), sbb)
+
+        def S(th):
+            o = torch.stack([lpt(R.T(x[b]), th, sb[b]) for b in range(B)])
+            return (R.T(w_re) * o[:, 0] + R.T(w_im) * o[:, 1]).sum()
+        gr = torch.func.grad(S)(R.T(theta)).numpy()
+        assert np.abs(g - gr).max() < 1e-10 * max(1.0, np.abs(gr).max())
+        qs = eng.quantum_score(x, sidx)
+        qr = R.make_quantum_score(lpt)(R.T(x), R.T(theta), sb).numpy()
+        assert np.abs(qs - qr).max() < 1e-10 * max(1.0, np.abs(qr).max())

@@ -89,3 +89,39 @@ def test_general_depth_device_code_vs_c_oracle(n, dim, depth, hs, ht, L):
     assert np.abs(out[:, 0] - ref[:, 0]).max() < 1e-11 * np.abs(ref[:, 0]).max()
     assert np.abs(np.angle(np.exp(1j * (out[:, 1] - ref[:, 1])))).max() < 1e-11
     assert np.abs(out[:, 2] - ref[:, 2]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n,dim,depth,hs,ht,L", [(4, 2, 3, 8, 4, 2.0), (3, 3, 4, 4, 6, 1.234), (5, 2, 2, 6, 6, 2.5)])
+def test_general_depth_param_vjp_vs_oracle(n, dim, depth, hs, ht, L):
+    """theta-VJP / per-sample scores of the general-depth path (cg_generic.hpp: dual-number reverse passes of the primal
+    flow) on the host shim against jacrev of the oracle's log Psi (main.py:277-278, src/logpsi.py:183-203)."""
+    import ctypes as C
+    import torch
+    from oracle import cg_ref as R
+    from tests.common import orbitals, flow_theta, state_indices, walkers
+    from tests.emul_engine import lib as emul_lib
+    p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    rng = np.random.default_rng(10 + depth)
+    sp = orbitals(dim)
+    B = 2
+    theta = flow_theta(rng, depth, hs, ht, dim, 0.4, 0.2)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    w_re, w_im = rng.standard_normal(B), rng.standard_normal(B)
+    g = np.zeros(theta.size)
+    npar = emul_lib().emu_gen_param_vjp(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B,
+                                        p(w_re), p(w_im), p(g), None)
+    assert npar == theta.size
+    rflow = R.FermiNet(depth, hs, ht, L)
+    r_logpsi = R.make_logpsi(rflow, sp, L)
+    sb = torch.as_tensor(sidx.astype(np.int64))
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, depth, hs, ht, dim), sbb)
+
+    def S(th):
+        out = torch.stack([lpt(R.T(x[b]), th, sb[b]) for b in range(B)])
+        return (R.T(w_re) * out[:, 0] + R.T(w_im) * out[:, 1]).sum()
+    gr = torch.func.grad(S)(R.T(theta)).numpy()
+    assert np.abs(g - gr).max() < 1e-10 * max(1.0, np.abs(gr).max())
+    sc = np.zeros((B, theta.size, 2))
+    emul_lib().emu_gen_param_vjp(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, None, None, None, p(sc))
+    qr = R.make_quantum_score(lpt)(R.T(x), R.T(theta), sb).numpy()
+    assert np.abs(sc[..., 0] + 1j * sc[..., 1] - qr).max() < 1e-10 * max(1.0, np.abs(qr).max())
