@@ -66,10 +66,21 @@ struct CgDerivs {
         w.total = t;
         return w;
     }
-    struct Layout { Ws w; Adj a; CgFastLds o; };
-    static Layout layout(int n) { Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false); return l; }
+    // oj: layout of the Jet2 arena of the directional passes.  When 3 * oj.total doubles fit the LDS (aliased sampler
+    // layout: the passes need primal + Jacobian lifetimes only) the arena lives there -- the passes are latency-bound on
+    // their ~25 barrier-separated phases and an L2 round trip per access made them ~10x slower than their arithmetic.
+    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; };
+    static constexpr size_t JET_LDS_MAX_BYTES = 150 * 1024;
+    static Layout layout(int n, int nthr = 256) {
+        Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
+        const CgFastLds al = cg_fast_layout(n, D, HS, HT, true, false);
+        l.jets_in_lds = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total) <= JET_LDS_MAX_BYTES ? 1 : 0;
+        l.oj = l.jets_in_lds ? al : l.o;
+        return l;
+    }
+    static size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
-    static size_t lds_doubles(int n, int nthr) { return (size_t)nthr + 16; }
+    static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }
 
     // ------------------------------------------------------------------------------------------------------
     // shared set-up: z, J, J^-1, D, D^-1, g_ia = d log phi / d z_ia.  Returns nothing; everything in ws.
@@ -134,9 +145,9 @@ struct CgDerivs {
 
     // one directional jet pass: fills the Jet2 arena (z, J as jets) for direction dir (N doubles, global/ws)
     static CG_DEVI void jet_pass(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                 const CgFastLds& o, const double* dir, int basis) {
+                                 const CgFastLds& o, Jet2* ja, const double* dir, int basis) {
         const int N = n * D;
-        Jet2* xj = (Jet2*)(ws + w.xj); Jet2* ja = (Jet2*)(ws + w.ja);
+        Jet2* xj = (Jet2*)(ws + w.xj);
         const double* x = ws + w.x;
         for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
         b.sync();
@@ -154,13 +165,14 @@ struct CgDerivs {
         setup(b, th, xg, spk, sidx, n, L, ws, w, o, true);
         const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
         const double* gz = ws + w.gz; double* M = ws + w.M;
-        const Jet2* ja = (const Jet2*)(ws + w.ja);
+        const CgFastLds& oj = lay.oj;
+        Jet2* ja = lay.jets_in_lds ? (Jet2*)(lds + lds_doubles(n, b.nthr)) : (Jet2*)(ws + w.ja);
         double lap_re = 0.0, lap_im = 0.0;
         const int ndir = N + (mode == 0 ? 0 : 1);
         for (int dir = 0; dir < ndir; ++dir) {
             const bool probe = dir == N;
-            jet_pass(b, th, n, L, ws, w, o, probe ? v : nullptr, dir);
-            const Jet2* zj = ja + o.z; const Jet2* Jj = ja + o.J;
+            jet_pass(b, th, n, L, ws, w, oj, ja, probe ? v : nullptr, dir);
+            const Jet2* zj = ja + oj.z; const Jet2* Jj = ja + oj.J;
             const bool want_phi2 = probe ? (mode == 1) : (mode == 0 || mode == 2);   // second derivative of log phi
             const bool want_jac2 = probe ? true : (mode == 0);                        // second derivative of 1/2 log|det J|
             // ---- Slater part

@@ -189,8 +189,9 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 #define CG_DERIV_WAVES 3
 #endif
 #define CG_DERIV_WAVES_OF(D) ((D) == 2 ? CG_DERIV_WAVES : (CG_DERIV_WAVES < 2 ? CG_DERIV_WAVES : 2))
-template <int D, int HS, int HT>
-__global__ void __launch_bounds__(256, CG_DERIV_WAVES_OF(D)) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+// JLDS: the Jet2 arena of the directional passes lives in LDS (2 workgroups per CU, so 2 waves/SIMD of registers).
+template <int D, int HS, int HT, bool JLDS>
+__global__ void __launch_bounds__(256, (JLDS ? (CG_DERIV_WAVES_OF(D) < 2 ? CG_DERIV_WAVES_OF(D) : 2) : CG_DERIV_WAVES_OF(D))) k_grad_lap(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
                            const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
                            double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
@@ -946,12 +947,20 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 #define CG_X(D, HS, HT)                                                                                              \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                      \
-        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt));                                \
+        const auto dl = CgDerivs<D, HS, HT>::layout(n, nt);                                                         \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::jet_lds_doubles(dl)); \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                            \
-        if ((rc = set_lds(c, k_grad_lap<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_grad_lap<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
-                           (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev,    \
-                           (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                                    \
+        if (dl.jets_in_lds) {                                                                                       \
+            if ((rc = set_lds(c, k_grad_lap<D, HS, HT, true>, lds))) return rc;                                     \
+            hipLaunchKernelGGL((k_grad_lap<D, HS, HT, true>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
+                               (double*)c->ws, wsw, dl);                                                            \
+        } else {                                                                                                    \
+            if ((rc = set_lds(c, k_grad_lap<D, HS, HT, false>, lds))) return rc;                                    \
+            hipLaunchKernelGGL((k_grad_lap<D, HS, HT, false>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
+                               (double*)c->ws, wsw, dl);                                                            \
+        }                                                                                                           \
         launched = true;                                                                                            \
     }
     CG_FAST_CONFIGS(CG_X)

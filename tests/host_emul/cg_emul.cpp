@@ -47,12 +47,13 @@ template <int D, int HS, int HT>
 static void emu_gradlap_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
                           const double* x, int B, int mode, const double* v, double* grad, double* lap) {
     using G = CgDerivs<D, HS, HT>;
-    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + 8), spk((size_t)M * D);
+    const auto lay = G::layout(n, 1);              // Jet arena in "LDS" (aliased layout) whenever the GPU kernel would
+    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + G::jet_lds_doubles(lay) + 8), spk((size_t)M * D);
     for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
     CgBlk b{0, 1};
     for (int w = 0; w < B; ++w)
         G::grad_laplacian(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
-                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data(), G::layout(n));
+                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data(), lay);
 }
 extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
                                   const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap) {
