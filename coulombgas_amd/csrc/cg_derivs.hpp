@@ -46,7 +46,7 @@ struct CgDerivs {
     }
     static size_t adj_doubles(int n) { return adj_layout(n).total; }
     struct Ws {   // offsets in doubles into the per-workgroup workspace
-        size_t da, ja, x, xj, Jc, Jinv, M, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, total;
+        size_t da, ja, x, xj, Jc, Jinv, M, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, zs, total;
     };
     static Ws ws_layout(int n) {
         const size_t N = (size_t)n * D;
@@ -63,6 +63,7 @@ struct CgDerivs {
         w.perm = take(N + 42);
         w.adj = take(adj_doubles(n));
         w.gw = take(NP);
+        w.zs = take(3 * N);               // z jets of a split pass (jet_pass_split)
         w.total = t;
         return w;
     }
@@ -155,6 +156,33 @@ struct CgDerivs {
         F::jacobian(b, th, n, L, ja, o);
     }
 
+    // Basis-direction pass of the Hutchinson-split mode: z', z'' from the Jet2 primal, J' from a first-order (Dual)
+    // Jacobian assembly.  The Dual arena reuses the Jet2 arena's memory (2/3 of it): the four persistent primal arrays
+    // the assembly reads (sh, ch, sg1, sg2) are carried over through registers, z jets are saved to zsave first.
+    static CG_DEVI void jet_pass_split(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
+                                       const CgFastLds& o, Jet2* ja, Jet2* zsave, int basis) {
+        const int N = n * D;
+        Jet2* xj = (Jet2*)(ws + w.xj);
+        const double* x = ws + w.x;
+        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], e == basis ? 1.0 : 0.0, 0.0);
+        b.sync();
+        F::primal(b, th, (const Jet2*)xj, n, L, ja, o);
+        Dual* da2 = (Dual*)ja;
+        const int cnt[4] = {N, N, n * HS, n * HS};
+        const int off[4] = {o.sh, o.ch, o.sg1, o.sg2};
+        for (int e = b.tid; e < N; e += b.nthr) zsave[e] = ja[o.z + e];
+        // carry sh, ch, sg1, sg2 over in chunks of nthr elements (read all, barrier, write all: the arenas overlap)
+        for (int q = 0; q < 4; ++q)
+            for (int e0 = 0; e0 < cnt[q]; e0 += b.nthr) {
+                const int e = e0 + b.tid;
+                Jet2 v; if (e < cnt[q]) v = ja[off[q] + e];
+                b.sync();
+                if (e < cnt[q]) da2[off[q] + e] = Dual(v.v, v.d);
+                b.sync();
+            }
+        F::jacobian(b, th, n, L, da2, o);
+    }
+
     static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                                        const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                                        int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
@@ -171,8 +199,11 @@ struct CgDerivs {
         const int ndir = N + (mode == 0 ? 0 : 1);
         for (int dir = 0; dir < ndir; ++dir) {
             const bool probe = dir == N;
-            jet_pass(b, th, n, L, ws, w, oj, ja, probe ? v : nullptr, dir);
-            const Jet2* zj = ja + oj.z; const Jet2* Jj = ja + oj.J;
+            const bool split = !probe && mode == 2;        // only J' is needed: first-order Jacobian jets
+            if (split) jet_pass_split(b, th, n, L, ws, w, oj, ja, (Jet2*)(ws + w.zs), dir);
+            else jet_pass(b, th, n, L, ws, w, oj, ja, probe ? v : nullptr, dir);
+            const Jet2* zj = split ? (const Jet2*)(ws + w.zs) : ja + oj.z;
+            const Jet2* Jj = ja + oj.J; const Dual* Jd = (const Dual*)ja + oj.J;
             const bool want_phi2 = probe ? (mode == 1) : (mode == 0 || mode == 2);   // second derivative of log phi
             const bool want_jac2 = probe ? true : (mode == 0);                        // second derivative of 1/2 log|det J|
             // ---- Slater part
@@ -208,7 +239,7 @@ struct CgDerivs {
             for (int e = b.tid; e < N * N; e += b.nthr) {
                 const int al = e / N, ga = e - al * N;
                 const double ji = Jinv[al * N + ga];
-                t1 += ji * Jj[ga * N + al].d;
+                t1 += ji * (split ? Jd[ga * N + al].d : Jj[ga * N + al].d);
                 if (want_jac2) t2 += ji * Jj[ga * N + al].dd;
             }
             if (want_jac2) {
