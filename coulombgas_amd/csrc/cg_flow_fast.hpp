@@ -928,21 +928,13 @@ struct CgFast {
             half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
             b.sync();
             CG_STAMP(14)
-        } else if (o.Dm != o.J) {
-            // mid sizes: single-wave LDS LUs, real on wave 0 and complex on wave 1 concurrently
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
-            double* res = (double*)perm;
-            const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
-            if (wave == 0) { const double v = cg_wave_lds_lu_logabsdet(lds + o.J, n * D, n * D); if (b.tid == 0) res[0] = v; }
-            if (wave == cw) { double l2, a2; cg_wave_lds_lu_logdet_complex(lds + o.Dm, n, n, l2, a2); if ((b.tid & 63) == 0) { res[1] = l2; res[2] = a2; } }
-            b.sync();
-            half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
-            b.sync();
         } else {
-            // largest sizes (Slater matrix shares J's LDS): the whole workgroup, one determinant after the other
-            half_logdetJ = 0.5 * cg_lu_logabsdet(b, lds + o.J, n * D, n * D, perm, nullptr, true);
+            // larger sizes: workgroup-wide blocked LUs (4-column panels on wave 0, MFMA trailing updates on every wave).
+            // The Slater matrix may share J's LDS (o.Dm == o.J), so it is formed after the real factorisation.
+            double* res = (double*)perm;
+            half_logdetJ = 0.5 * cg_blocked_lu_logabsdet(b, lds + o.J, n * D, n * D, res);
             slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
-            cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar, true);
+            cg_blocked_lu_logdet_complex(b, lds + o.Dm, n, n, res, la, ar);
         }
 #else
         {
