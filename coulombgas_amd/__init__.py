@@ -1,7 +1,7 @@
 """coulombgas_amd -- MI355X-native VMC hot path of fermiflow/CoulombGas.
 
 Exports the names main.py takes from the reference's `src` package for this path
-(src/__init__.py:1-13); everything else of the reference (Transformer sampler, SR optimizer,
+(src/__init__.py:1-13) plus the SR optimizer (src/sr.py); everything else of the reference (Transformer sampler,
 checkpointing, pre-training) is outside the accelerated path."""
 from .flow import FermiNet
 from .potential import kpoints, Madelung, potential_energy
@@ -9,9 +9,11 @@ from .logpsi import (make_logpsi, make_logphi_logjacdet, make_logpsi_grad_laplac
                      make_quantum_score)
 from .mcmc import mcmc
 from .vmc import sample_stateindices_and_x, make_loss, make_observable
+from .sr import fisher_sr, hybrid_fisher_sr, apply_updates
 from .utils import shard, replicate
 from .engine import Engine
 
 __all__ = ["FermiNet", "kpoints", "Madelung", "potential_energy", "make_logpsi", "make_logphi_logjacdet",
            "make_logpsi_grad_laplacian", "make_logp", "make_quantum_score", "mcmc",
-           "sample_stateindices_and_x", "make_loss", "make_observable", "shard", "replicate", "Engine"]
+           "sample_stateindices_and_x", "make_loss", "make_observable", "fisher_sr", "hybrid_fisher_sr", "apply_updates",
+           "shard", "replicate", "Engine"]

@@ -239,6 +239,56 @@ __global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int 
     out[p] = a;
 }
 
+// Quantum Fisher matrix of stochastic reconfiguration (src/sr.py:74-76):  F[p][q] = (1/B) sum_b Re( conj(S[b][p]) S[b][q] )
+// = (1/B) sum_b ( Sr[b][p] Sr[b][q] + Si[b][p] Si[b][q] ),  S = per-sample scores (B x P, complex interleaved).
+// One wave per 16 x 16 tile of the upper triangle (mirrored on store); the batch axis is the K of v_mfma_f64_16x16x4.
+__global__ void __launch_bounds__(256) k_fisher(const double* __restrict__ S, int B, int P, double* __restrict__ F) {
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles = (P + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles * tiles) return;
+    const int ti = tile / tiles, tj = tile - ti * tiles;
+    if (tj < ti) return;
+    const int col = lane & 15, kq = lane >> 4;
+    const int p = 16 * ti + col, q = 16 * tj + col;
+    const bool pok = p < P, qok = q < P;
+    d4_t acc = {0, 0, 0, 0};
+    for (int b1 = 0; b1 < B; b1 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // four independent load groups in flight per trip
+            const int b = b1 + 4 * u + kq;
+            const bool bok = b < B;
+            const double* sa = S + ((size_t)b * P + p) * 2;
+            const double* sb = S + ((size_t)b * P + q) * 2;
+            const double a_re = (bok && pok) ? sa[0] : 0.0, a_im = (bok && pok) ? sa[1] : 0.0;
+            const double b_re = (bok && qok) ? sb[0] : 0.0, b_im = (bok && qok) ? sb[1] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, b_re, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, b_im, acc, 0, 0, 0);
+        }
+    }
+    const double rb = 1.0 / (double)B;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pr = 16 * ti + kq + 4 * r;
+        if (pr < P && qok) {
+            const double v = acc[r] * rb;
+            F[(size_t)pr * P + q] = v;
+            if (ti != tj) F[(size_t)q * P + pr] = v;
+        }
+    }
+}
+// mean over the batch of the complex scores (src/sr.py:70): out[2 p + c] = (1/B) sum_b S[b][p][c]; fixed summation order
+__global__ void __launch_bounds__(256) k_score_mean(const double* __restrict__ S, int B, int P2 /* 2 P */, double* __restrict__ out) {
+    __shared__ double part[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    double a = 0.0;
+    if (c < P2) for (int b = rg; b < B; b += 4) a += S[(size_t)b * P2 + c];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && c < P2) out[c] = (part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]) / (double)B;
+}
+
 __global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) buf[i] *= s;
@@ -971,7 +1021,7 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 }
 
 static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
-                   const double* w_im, double* g_theta, double* score) {
+                   const double* w_im, double* g_theta, double* score, double* fisher = nullptr, double* smean = nullptr) {
     int rc = check_ready(c, fn, B); if (rc) return rc;
     const int n = c->n, N = n * c->dim, P = c->P;
     if (B == 0) {
@@ -987,8 +1037,14 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     Arg awi{(void*)w_im, nullptr, sizeof(double) * (size_t)B, true, false};
     Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
     Arg asc{score, nullptr, sizeof(double) * (size_t)B * P * 2, false, true};
-    Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc};
+    Arg afi{fisher, nullptr, sizeof(double) * (size_t)P * P, false, true};
+    Arg asm_{smean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
+    Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc, &afi, &asm_};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    if (fisher && !asc.dev) {        // the scores of the Fisher matrix stay on the device
+        asc.dev = arena_take(c, asc.bytes);
+        if (!asc.dev) CG_FAIL(c, CG_ERR_HIP, "%s: %zu bytes for the per-sample scores could not be allocated", fn, asc.bytes);
+    }
     const int nt = 256;
     const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
     double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
@@ -1018,6 +1074,11 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
     if (g_theta)
         hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
+    if (fisher) {
+        const int tiles = (P + 15) / 16;
+        hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)asc.dev, B, P, (double*)afi.dev);
+        if (smean) hipLaunchKernelGGL(k_score_mean, dim3((2 * P + 63) / 64), dim3(256), 0, c->stream, (const double*)asc.dev, B, 2 * P, (double*)asm_.dev);
+    }
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
 }
@@ -1030,6 +1091,11 @@ int cg_param_vjp(cg_ctx* c, const double* x, const int32_t* sidx, int B, const d
 int cg_quantum_score(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* score) {
     if (c && !score) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_score: score is NULL");
     return run_vjp(c, "cg_quantum_score", x, sidx, B, nullptr, nullptr, nullptr, score);
+}
+int cg_quantum_fisher(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* fisher, double* score_mean) {
+    if (c && (!fisher || !score_mean)) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: NULL output");
+    if (c && B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: empty batch");
+    return run_vjp(c, "cg_quantum_fisher", x, sidx, B, nullptr, nullptr, nullptr, nullptr, fisher, score_mean);
 }
 
 

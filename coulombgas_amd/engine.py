@@ -237,6 +237,15 @@ class Engine:
         check(lib().cg_quantum_score(self._ctx, _p(xb), _p(s), B, _p(sc)), self._ctx)
         return (sc[..., 0] + 1j * sc[..., 1]).reshape(lead + (self.P,))
 
+    def quantum_fisher(self, x, state_idx):
+        """fishers_fn of src/sr.py:62-80 for this device: (Re(S^H S)/B (P,P), mean_b S (P,) complex)."""
+        xb, _ = self._xb(x)
+        B = xb.shape[0]
+        s = self._sb(state_idx, B)
+        F = np.empty((self.P, self.P)); sm = np.empty((self.P, 2))
+        check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
+        return F, sm[:, 0] + 1j * sm[:, 1]
+
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):
         assert self._mode == _lib.CG_PTR_DEVICE

@@ -1,0 +1,114 @@
+"""Host-side mirror of src/sr.py (stochastic reconfiguration), API in parallel with the reference's optax-style
+`GradientTransformation(init, update)`.
+
+The Fisher matrices are where the work is: the quantum one, Re(S^H S)/B over the per-sample scores
+S = d log Psi / d theta (src/logpsi.py:183-203), is formed on the GPU (cg_quantum_fisher: reverse passes for the
+scores, f64 MFMA SYRK, all on the device).  The (P x P) damped solves and the norm clip (src/sr.py:102-117) are host
+LAPACK calls once per optimisation step.  The classical score function (the autoregressive Transformer, outside the
+accelerated path) is supplied by the caller and returns a (B, P_van) array (or a pytree of arrays with a leading
+batch axis, ravelled in sorted-key order like jax's ravel_pytree)."""
+from collections import namedtuple
+import numpy as np
+from .comm import get_comm
+
+GradientTransformation = namedtuple("GradientTransformation", ["init", "update"])
+EmptyState = namedtuple("EmptyState", [])
+
+
+def ravel_pytree(tree):
+    """jax.flatten_util.ravel_pytree for nested dicts of arrays (leaves in sorted-key order).  Returns flat, unravel."""
+    if isinstance(tree, np.ndarray) or np.isscalar(tree):
+        a = np.asarray(tree)
+        return a.reshape(-1), (lambda f, shp=a.shape: np.asarray(f).reshape(shp))
+    keys = sorted(tree)
+    parts = [ravel_pytree(tree[k]) for k in keys]
+    sizes = [p[0].size for p in parts]
+    flat = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0)
+
+    def unravel(f):
+        out, off = {}, 0
+        for k, (_, un), sz in zip(keys, parts, sizes):
+            out[k] = un(f[off:off + sz]); off += sz
+        return out
+    return flat, unravel
+
+
+def _ravel_batched(score):
+    """jax.vmap(lambda pytree: ravel_pytree(pytree)[0])(score): (B, P)."""
+    if isinstance(score, np.ndarray):
+        return score.reshape(score.shape[0], -1)
+    keys = sorted(score)
+    return np.concatenate([_ravel_batched(score[k]) for k in keys], axis=1)
+
+
+def _solve_and_clip(fisher, grads_raveled, damping, max_norm):
+    """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1)."""
+    from scipy.linalg import solve
+    fisher = fisher + damping * np.eye(fisher.shape[0])
+    upd = solve(fisher, grads_raveled, assume_a="sym")
+    gnorm = float(np.sum(grads_raveled * upd))
+    scale = min(np.sqrt(max_norm / gnorm), 1.0) if gnorm > 0 else 1.0
+    return -scale * upd
+
+
+def fisher_sr(score_fn, damping, max_norm):
+    """src/sr.py:13-52: natural gradient for a purely classical model.  update(grads, state, (params, state_indices))."""
+    def init_fn(params):
+        return EmptyState()
+
+    def update_fn(grads, state, params):
+        params, state_indices = params
+        g, unravel = ravel_pytree(grads)
+        score = _ravel_batched(score_fn(params, state_indices))
+        fisher = score.T.dot(score) / score.shape[0]
+        return unravel(_solve_and_clip(fisher, g, damping, max_norm)), state
+
+    return GradientTransformation(init_fn, update_fn)
+
+
+def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, comm=None):
+    """src/sr.py:56-122.  Returns (fishers_fn, optimizer) like the reference.
+    fishers_fn(params_van, params_flow, state_indices, x) -> (classical_fisher, quantum_fisher, quantum_score_mean), each
+    averaged over the ranks (the reference's pmean, :70-76).  `quantum_score_fn` is make_quantum_score(logpsi): its wave
+    function's engine computes Re(S^H S)/B and mean(S) on the GPU without moving the (B, P) score matrix to the host."""
+    wf = quantum_score_fn.wf
+
+    def fishers_fn(params_van, params_flow, state_indices, x):
+        cm = comm or get_comm()
+        classical_fisher = None
+        if classical_score_fn is not None:
+            cs = _ravel_batched(classical_score_fn(params_van, state_indices))
+            classical_fisher = cm.pmean(cs.T.dot(cs) / cs.shape[0])
+        eng = wf.engine(x, params_flow)
+        qf, qmean = eng.quantum_fisher(x, state_indices)
+        packed = cm.pmean(np.concatenate([qf.reshape(-1), qmean.real, qmean.imag]))      # one all-reduce
+        P = qmean.shape[0]
+        return classical_fisher, packed[:P * P].reshape(P, P), packed[P * P:P * P + P] + 1j * packed[P * P + P:]
+
+    def init_fn(params):
+        return EmptyState()
+
+    def update_fn(grads, state, params):
+        grad_params_van, grad_params_flow = grads
+        classical_fisher, quantum_fisher, quantum_score_mean = params
+        quantum_fisher = quantum_fisher - (quantum_score_mean.conj()[:, None] * quantum_score_mean).real   # :88
+        update_van = None
+        if grad_params_van is not None and classical_fisher is not None:
+            gv, unravel_van = ravel_pytree(grad_params_van)
+            update_van = unravel_van(_solve_and_clip(classical_fisher, gv, damping, max_norm))
+        gf, unravel_flow = ravel_pytree(grad_params_flow)
+        update_flow = unravel_flow(_solve_and_clip(quantum_fisher, gf, damping, max_norm))
+        return (update_van, update_flow), state
+
+    return fishers_fn, GradientTransformation(init_fn, update_fn)
+
+
+def apply_updates(params, updates):
+    """optax.apply_updates for nested dicts of arrays (None entries pass through)."""
+    if updates is None:
+        return params
+    if isinstance(params, dict):
+        return {k: apply_updates(params[k], updates[k]) for k in params}
+    if isinstance(params, (tuple, list)):
+        return type(params)(apply_updates(p, u) for p, u in zip(params, updates))
+    return np.asarray(params) + np.asarray(updates)

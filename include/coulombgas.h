@@ -131,6 +131,9 @@ int cg_param_vjp(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B,
                  const double* w_re, const double* w_im, double* g_theta);
 /* per-sample scores S (B,P,2) complex = make_quantum_score(logpsi)  (src/logpsi.py:183-203) */
 int cg_quantum_score(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* score);
+/* Quantum Fisher matrix and mean score of the hybrid SR optimizer, fishers_fn of src/sr.py:62-80 for ONE device (before
+ * its pmean): fisher (P,P) = Re(S^H S) / B, score_mean (P,2) = mean_b S[b].  The scores stay on the device. */
+int cg_quantum_fisher(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* fisher, double* score_mean);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
 

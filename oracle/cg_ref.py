@@ -394,3 +394,28 @@ def quantum_loss_and_grads(logpsi_theta, theta, x, state_indices, Eloc_clipped):
     vals = lossfn(theta)
     J = jacrev(lossfn)(theta)
     return vals[0], vals[1], J[0], J[1]
+
+
+# --------------------------------------------------------------------------- #
+# src/sr.py
+# --------------------------------------------------------------------------- #
+def sr_solve_and_clip(fisher, grads_raveled, damping, max_norm):
+    """src/sr.py:38-45 and :102-117 (same statements for the classical and the quantum block), numpy."""
+    fisher = fisher + damping * np.eye(fisher.shape[0])
+    updates_raveled = np.linalg.solve(fisher, grads_raveled)
+    gnorm = np.sum(grads_raveled * updates_raveled)
+    scale = np.minimum(np.sqrt(max_norm / gnorm), 1)
+    return -scale * updates_raveled
+
+
+def hybrid_fisher_sr_update(classical_score, quantum_score, grad_van, grad_flow, damping, max_norm):
+    """src/sr.py:62-122 on one device (the pmeans are identities): classical_score (B,Pv) real, quantum_score (B,Pf)
+    complex, raveled gradients.  Returns (classical_fisher, quantum_fisher, quantum_score_mean, update_van, update_flow)."""
+    B = classical_score.shape[0]
+    quantum_score_mean = quantum_score.mean(axis=0)                                   # :70
+    classical_fisher = classical_score.T.dot(classical_score) / B                     # :74
+    quantum_fisher = quantum_score.conj().T.dot(quantum_score).real / B               # :76
+    qf = quantum_fisher - (quantum_score_mean.conj()[:, None] * quantum_score_mean).real      # :88
+    return (classical_fisher, quantum_fisher, quantum_score_mean,
+            sr_solve_and_clip(classical_fisher, grad_van, damping, max_norm),
+            sr_solve_and_clip(qf, grad_flow, damping, max_norm))

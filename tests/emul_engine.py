@@ -128,6 +128,10 @@ class EmulEngine:
         assert lib().emu_param_vjp(*self._args(), _p(s), _p(xb), B, None, None, None, _p(sc)) == 0
         return (sc[..., 0] + 1j * sc[..., 1]).reshape(lead + (self.P,))
 
+    def quantum_fisher(self, x, sidx):
+        sc = self.quantum_score(x, sidx).reshape(-1, self.P)
+        return (sc.conj().T @ sc).real / sc.shape[0], sc.mean(axis=0)
+
     def close(self):
         pass
 

@@ -402,3 +402,36 @@ def test_general_depth_against_oracle(n, dim, depth, hs, ht, L):
         qs = eng.quantum_score(x, sidx)
         qr = R.make_quantum_score(lpt)(R.T(x), R.T(theta), sb).numpy()
         assert np.abs(qs - qr).max() < 1e-10 * max(1.0, np.abs(qr).max())
+
+
+@pytest.mark.parametrize("case,depth", [((13, 2, 16, 16, None, 0.2, 0.1), 2), ((5, 2, 8, 4, 2.0, 0.4, 0.2), 3)])
+def test_quantum_fisher_and_sr_update(case, depth):
+    """cg_quantum_fisher (scores + f64 MFMA SYRK on the device) and the hybrid SR update (src/sr.py:56-122) against the
+    oracle: Re(S^H S)/B and mean(S) from jacrev scores, centring, damped solve, norm clip."""
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    n, dim, hs, ht, L, ws, bs = case
+    L = box_length(n, dim) if L is None else L
+    rng = np.random.default_rng(29)
+    sp = orbitals(dim)
+    B = 9
+    theta = flow_theta(rng, depth, hs, ht, dim, ws, bs)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    flow = cg.FermiNet(depth, hs, ht, L)
+    logpsi = cg.make_logpsi(flow, sp, L)
+    eng = flow.engine(n, dim, sp); eng.set_params(theta)
+    F, sm = eng.quantum_fisher(x, sidx)
+    rflow = R.FermiNet(depth, hs, ht, L)
+    r_logpsi = R.make_logpsi(rflow, sp, L)
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, depth, hs, ht, dim), sbb)
+    qs = R.make_quantum_score(lpt)(R.T(x), R.T(theta), torch.as_tensor(sidx.astype(np.int64))).numpy()
+    Fr = (qs.conj().T @ qs).real / B
+    assert np.abs(F - Fr).max() < 1e-10 * np.abs(Fr).max() and np.abs(F - F.T).max() == 0.0
+    assert np.abs(sm - qs.mean(axis=0)).max() < 1e-10 * np.abs(qs).max()
+    fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(logpsi), 1e-3, 1e-3)
+    params_flow = flow.unravel(theta, dim)
+    cf, qf, qm = fishers_fn(None, params_flow, sidx, x)
+    g = rng.standard_normal(theta.size)
+    (_, u_flow), _ = opt.update((None, flow.unravel(g, dim)), opt.init(None), (cf, qf, qm))
+    ref = R.hybrid_fisher_sr_update(np.zeros((B, 1)) + 1.0, qs, np.ones(1), g, 1e-3, 1e-3)[4]
+    assert np.abs(flow.ravel(u_flow, dim) - ref).max() < 1e-6 * np.abs(ref).max()

@@ -133,3 +133,44 @@ def test_sample_stateindices_and_x(monkeypatch):
     assert np.array_equal(x, x_again) and rate == rate_again
     with pytest.raises(TypeError):
         cg.mcmc(lambda xx: xx, pb["x"], 0, 3, 0.1)          # an opaque callable cannot run in the GPU chain: no fallback
+
+
+def test_hybrid_fisher_sr_against_oracle(monkeypatch):
+    """src/sr.py:56-122 (+ fisher_sr :13-52): Fisher matrices, centring, damped solves and the norm clip of the host mirror
+    (engine = host emulation of the device code) against the oracle's statement-by-statement restatement, with the
+    per-sample scores of the oracle's jacrev."""
+    emul_engine.install(monkeypatch)
+    n, dim, hs, ht, B = 5, 2, 4, 4, 12
+    L = 2.0
+    rng = np.random.default_rng(23)
+    sp = orbitals(dim)
+    theta = flow_theta(rng, 2, hs, ht, dim, 0.4, 0.2)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    flow = cg.FermiNet(2, hs, ht, L)
+    params_flow = flow.unravel(theta, dim)
+    logpsi = cg.make_logpsi(flow, sp, L)
+    qscore = cg.make_quantum_score(logpsi)
+    Pv = 7
+    cs = rng.standard_normal((B, Pv))
+    classical_score_fn = lambda params_van, state_indices: {"b": cs[:, 4:], "a": cs[:, :4].reshape(B, 2, 2)}   # a pytree
+    damping, max_norm = 1e-3, 1e-3
+    fishers_fn, opt = cg.hybrid_fisher_sr(classical_score_fn, qscore, damping, max_norm)
+    cf, qf, qm = fishers_fn(None, params_flow, sidx, x)
+    g_van = {"a": rng.standard_normal((2, 2)), "b": rng.standard_normal(3)}
+    g_flow = flow.unravel(rng.standard_normal(theta.size), dim)
+    (u_van, u_flow), _ = opt.update((g_van, g_flow), opt.init(None), (cf, qf, qm))
+    # oracle
+    rflow = R.FermiNet(2, hs, ht, L)
+    r_logpsi = R.make_logpsi(rflow, sp, L)
+    lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, 2, hs, ht, dim), sbb)
+    qs = R.make_quantum_score(lpt)(R.T(x), R.T(theta), torch.as_tensor(sidx.astype(np.int64))).numpy()
+    gv = np.concatenate([g_van["a"].ravel(), g_van["b"].ravel()])
+    rcf, rqf, rqm, ruv, ruf = R.hybrid_fisher_sr_update(cs, qs, gv, flow.ravel(g_flow, dim), damping, max_norm)
+    assert np.abs(cf - rcf).max() < 1e-13 and np.abs(qf - rqf).max() < 1e-9 * np.abs(rqf).max() and np.abs(qm - rqm).max() < 1e-10 * np.abs(rqm).max()
+    assert np.abs(np.concatenate([u_van["a"].ravel(), u_van["b"].ravel()]) - ruv).max() < 1e-9 * np.abs(ruv).max()
+    assert np.abs(flow.ravel(u_flow, dim) - ruf).max() < 1e-7 * np.abs(ruf).max()
+    new = cg.apply_updates(params_flow, u_flow)
+    assert np.allclose(flow.ravel(new, dim), theta + flow.ravel(u_flow, dim))
+    # fisher_sr (purely classical natural gradient)
+    upd, _ = cg.fisher_sr(classical_score_fn, damping, max_norm).update(g_van, None, (None, sidx))
+    assert np.abs(np.concatenate([upd["a"].ravel(), upd["b"].ravel()]) - R.sr_solve_and_clip(rcf, gv, damping, max_norm)).max() < 1e-9 * np.abs(ruv).max()

@@ -23,3 +23,4 @@ t("grad_lap hutchinson-split", lambda: eng.grad_laplacian(x, sidx, 2, v))
 t("grad_lap exact", lambda: eng.grad_laplacian(x[:B // 4], sidx[:B // 4], 0), reps=1)
 w = np.ones(B)
 t("param_vjp", lambda: eng.param_vjp(x, sidx, w, 0.5 * w))
+t("quantum_fisher (scores+SYRK)", lambda: eng.quantum_fisher(x, sidx), reps=1)
