@@ -1,0 +1,167 @@
+"""The training loop of main.py:216-384 for one process per GPU, on top of the accelerated hot path.
+
+`update` mirrors main.py:263-310 (jacrev of the two loss closures, pmean, accumulation over acc_steps, the final-step
+algebra grad - <F> score / grad - <E> score, optimizer step); `train` mirrors the epoch loop (:316-384) including the
+thermalisation rounds (:241-246) and the data.txt row format (:367-372).
+
+The variational density matrix (autoregressive Transformer, src/autoregressive.py + src/sampler.py) is outside the
+accelerated path: the caller passes `sampler`, `log_prob` and -- if params_van is to be trained -- `log_prob_vjp`
+(the vector-Jacobian product jax.jacrev(classical_lossfn) needs) and `classical_score_fn`.  `GroundStateSampler`
+is the trivial stand-in (zero temperature: every walker in the n lowest orbitals, log_prob = 0)."""
+import numpy as np
+from . import sr as _sr
+from .comm import get_comm
+from .vmc import sample_stateindices_and_x, make_loss
+from .logpsi import make_logpsi, make_logphi_logjacdet, make_logp, make_logpsi_grad_laplacian, make_quantum_score
+from .potential import kpoints, Madelung
+
+DATA_KEYS = ("F_mean", "F2_mean", "E_mean", "E2_mean", "K_mean", "K2_mean", "V_mean", "V2_mean", "S_mean", "S2_mean")
+
+
+class GroundStateSampler:
+    """Zero-temperature stand-in for the autoregressive sampler: the n lowest orbitals of the (reversed, main.py:88-90)
+    table, i.e. its last n rows, for every walker; log-probability 0."""
+    def __init__(self, n, num_orbitals):
+        self.idx = np.arange(num_orbitals - n, num_orbitals, dtype=np.int32)
+
+    def __call__(self, params_van, key, batch):
+        return np.tile(self.idx, (batch, 1))
+
+    def log_prob(self, params_van, state_indices):
+        return np.zeros(np.shape(state_indices)[0])
+
+
+def adam(lr, b1=0.9, b2=0.999, eps=1e-8):
+    """optax.adam(lr) (main.py:186) for nested dicts / tuples of arrays; None leaves pass through."""
+    def tmap(f, *trees):
+        t0 = trees[0]
+        if t0 is None:
+            return None
+        if isinstance(t0, dict):
+            return {k: tmap(f, *[t[k] for t in trees]) for k in t0}
+        if isinstance(t0, (tuple, list)):
+            return type(t0)(tmap(f, *ts) for ts in zip(*trees))
+        return f(*[np.asarray(t) for t in trees])
+
+    def init_fn(params):
+        z = tmap(np.zeros_like, params)
+        return {"count": 0, "mu": z, "nu": tmap(np.zeros_like, params)}
+
+    def update_fn(grads, state, params=None):
+        c = state["count"] + 1
+        mu = tmap(lambda m, g: b1 * m + (1 - b1) * g, state["mu"], grads)
+        nu = tmap(lambda v, g: b2 * v + (1 - b2) * g * g, state["nu"], grads)
+        upd = tmap(lambda m, v: -lr * (m / (1 - b1 ** c)) / (np.sqrt(v / (1 - b2 ** c)) + eps), mu, nu)
+        return upd, {"count": c, "mu": mu, "nu": nu}
+
+    return _sr.GradientTransformation(init_fn, update_fn)
+
+
+def _tree(f, *trees):
+    t0 = trees[0]
+    if t0 is None:
+        return None
+    if isinstance(t0, dict):
+        return {k: _tree(f, *[t[k] for t in trees]) for k in t0}
+    if isinstance(t0, (tuple, list)):
+        return type(t0)(_tree(f, *ts) for ts in zip(*trees))
+    return f(*trees)
+
+
+def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, log_prob_vjp=None, comm=None):
+    """main.py:263-310.  Returns update(params_van, params_flow, opt_state, state_indices, x, key, acc, final_step) ->
+    (params_van, params_flow, opt_state, acc) with acc the dict of accumulators the reference threads through pmap."""
+    def new_acc():
+        return {"data": {k: 0.0 for k in DATA_KEYS}, "grads": None, "scores": None, "fishers": None}
+
+    def update(params_van, params_flow, opt_state, state_indices, x, key, acc, final_step):
+        cm = comm or get_comm()
+        acc = acc or new_acc()
+        data, classical_lossfn, quantum_lossfn = observable_and_lossfn(params_van, params_flow, state_indices, x, key)
+        grad_flow, score_flow = quantum_lossfn.grad(params_flow)                       # :278
+        grad_van = score_van = None
+        if log_prob_vjp is not None and params_van is not None:                        # :277
+            classical_lossfn(params_van)
+            grad_van = log_prob_vjp(params_van, state_indices, classical_lossfn.weights)
+            score_van = log_prob_vjp(params_van, state_indices, classical_lossfn.score_weights)
+        flat, unravel = _sr.ravel_pytree({"g": (grad_flow if grad_van is None else {"v": grad_van, "f": grad_flow}),
+                                          "s": (score_flow if score_van is None else {"v": score_van, "f": score_flow})})
+        tree = unravel(cm.pmean(flat))                                                 # :280, one packed all-reduce
+        grads, scores = tree["g"], tree["s"]
+        acc["data"] = {k: acc["data"][k] + data[k] for k in DATA_KEYS}                 # :281-283
+        acc["grads"] = grads if acc["grads"] is None else _tree(lambda a, b: a + b, acc["grads"], grads)
+        acc["scores"] = scores if acc["scores"] is None else _tree(lambda a, b: a + b, acc["scores"], scores)
+        if fishers_fn is not None:                                                     # :285-289
+            f = fishers_fn(params_van, params_flow, state_indices, x)
+            acc["fishers"] = f if acc["fishers"] is None else tuple(None if a is None else a + b for a, b in zip(acc["fishers"], f))
+        if final_step:                                                                 # :291-307
+            d = {k: v / acc_steps for k, v in acc["data"].items()}
+            g = _tree(lambda a: a / acc_steps, acc["grads"]); s = _tree(lambda a: a / acc_steps, acc["scores"])
+            if grad_van is None:
+                g_flow = _tree(lambda a, b: a - d["E_mean"] * b, g, s); g_van = None
+            else:
+                g_van = _tree(lambda a, b: a - d["F_mean"] * b, g["v"], s["v"])
+                g_flow = _tree(lambda a, b: a - d["E_mean"] * b, g["f"], s["f"])
+            fish = None if acc["fishers"] is None else tuple(None if a is None else a / acc_steps for a in acc["fishers"])
+            updates, opt_state = optimizer.update((g_van, g_flow), opt_state, params=fish)
+            if updates[0] is not None:
+                params_van = _sr.apply_updates(params_van, updates[0])
+            params_flow = _sr.apply_updates(params_flow, updates[1])
+            acc = dict(acc, data=d, grads=(g_van, g_flow))
+        return params_van, params_flow, opt_state, acc
+
+    update.new_acc = new_acc
+    return update
+
+
+def format_row(i, data, rs, batch_total, acc_steps, accept_rate):
+    """The data.txt row of main.py:352-372 (energies in Ry / rs^2)."""
+    out = []
+    for k in ("F", "E", "K", "V", "S"):
+        m, m2 = data[k + "_mean"], data[k + "2_mean"]
+        std = np.sqrt(max(m2 - m * m, 0.0) / (batch_total * acc_steps))
+        sc = 1.0 if k == "S" else 1.0 / rs ** 2
+        out += [m * sc, std * sc]
+    return ("%6d" + "  %.6f" * 10 + "  %.4f") % ((i,) + tuple(out) + (accept_rate,))
+
+
+def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sampler, log_prob, params_van=None,
+          optimizer=None, sr=None, kappa=10, Gmax=15, mc_therm=10, mc_steps=50, mc_stddev=0.1, acc_steps=1,
+          hutchinson=True, seed=42, log=None, log_prob_vjp=None, classical_score_fn=None, comm=None):
+    """main.py:216-384 on one rank.  sr = (damping, max_norm) selects hybrid_fisher_sr (main.py:179-184), otherwise
+    `optimizer` (default adam(1e-3)).  Returns (params_van, params_flow, rows) with rows the data.txt lines."""
+    cm = comm or get_comm()
+    G = kpoints(dim, Gmax)
+    Vconst = n * rs / L * Madelung(dim, kappa, G)                                      # :170-171
+    logpsi_novmap = make_logpsi(flow, sp_indices, L)
+    logphi, logjacdet = make_logphi_logjacdet(flow, sp_indices, L)
+    logp = make_logp(logpsi_novmap)
+    fishers_fn = None
+    if sr is not None:
+        fishers_fn, optimizer = _sr.hybrid_fisher_sr(classical_score_fn, make_quantum_score(logpsi_novmap), sr[0], sr[1], comm=cm)
+    elif optimizer is None:
+        optimizer = adam(1e-3)
+    opt_state = optimizer.init((params_van, params_flow))
+    ss = np.random.SeedSequence(seed).spawn(cm.world)[cm.rank]                        # :237, one key per device
+    rng = np.random.default_rng(ss)
+    x = rng.uniform(0.0, L, (batch, n, dim))                                           # :236
+    key = ss
+    for _ in range(mc_therm):                                                          # :241-246
+        key, _, x, _ = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc_steps, mc_stddev, L, comm=cm)
+    logpsi, lgl = make_logpsi_grad_laplacian(logpsi_novmap, hutchinson=hutchinson, logphi=logphi, logjacdet=logjacdet)   # :254-256
+    observable_and_lossfn = make_loss(log_prob, logpsi, lgl, kappa, G, L, rs, Vconst, beta, comm=cm)               # :258-259
+    update = make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn, log_prob_vjp, comm=cm)
+    rows = []
+    for i in range(1, epochs + 1):                                                     # :316-372
+        acc, accept_acc = update.new_acc(), 0.0
+        for a in range(acc_steps):
+            key, state_indices, x, accept_rate = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow,
+                                                                           mc_steps, mc_stddev, L, comm=cm)
+            accept_acc += accept_rate
+            params_van, params_flow, opt_state, acc = update(params_van, params_flow, opt_state, state_indices, x,
+                                                             key.spawn(1)[0], acc, a == acc_steps - 1)
+        row = format_row(i, acc["data"], rs, batch * cm.world, acc_steps, accept_acc / acc_steps)
+        rows.append(row)
+        if log is not None and cm.rank == 0:
+            log(row)
+    return params_van, params_flow, rows

@@ -174,3 +174,23 @@ def test_hybrid_fisher_sr_against_oracle(monkeypatch):
     # fisher_sr (purely classical natural gradient)
     upd, _ = cg.fisher_sr(classical_score_fn, damping, max_norm).update(g_van, None, (None, sidx))
     assert np.abs(np.concatenate([upd["a"].ravel(), upd["b"].ravel()]) - R.sr_solve_and_clip(rcf, gv, damping, max_norm)).max() < 1e-9 * np.abs(ruv).max()
+
+
+def test_training_loop_runs_and_logs(monkeypatch):
+    """main.py:216-384 mirror (coulombgas_amd/driver.py) end to end on the host emulation: thermalisation, two epochs with
+    gradient accumulation, both optimizers, data.txt row format (main.py:367-372)."""
+    emul_engine.install(monkeypatch)
+    n, dim, L = 4, 2, 2.0
+    sp = orbitals(dim)
+    flow = cg.FermiNet(2, 4, 4, L)
+    p0 = flow.init(3, np.zeros((n, dim)))
+    samp = cg.GroundStateSampler(n, sp.shape[0])
+    for kw in (dict(sr=(1e-3, 1e-3)), dict(optimizer=cg.adam(1e-2))):
+        pv, pf, rows = cg.train(flow, p0, sp, n, dim, L, rs=2.0, beta=1 / (4 * 0.15), batch=8, epochs=2, sampler=samp,
+                                log_prob=samp.log_prob, mc_therm=1, mc_steps=3, acc_steps=2, seed=1, **kw)
+        assert pv is None and len(rows) == 2
+        vals = [float(v) for v in rows[-1].split()]
+        assert len(vals) == 12 and int(vals[0]) == 2 and all(np.isfinite(vals)) and 0.0 <= vals[-1] <= 1.0
+        assert vals[9] == 0.0                                   # entropy of the zero-temperature sampler
+        assert abs(vals[1] - vals[3]) < 1e-6                    # F = E when S = 0
+        assert not np.array_equal(flow.ravel(pf, dim), flow.ravel(p0, dim))
