@@ -289,6 +289,22 @@ __global__ void __launch_bounds__(256) k_score_mean(const double* __restrict__ S
     if (rg == 0 && c < P2) out[c] = (part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]) / (double)B;
 }
 
+// out[p] = sum_b ( w_re[b] Sre[b][p] + w_im[b] Sim[b][p] ): the theta-VJP from resident scores; fixed summation order
+__global__ void __launch_bounds__(256) k_score_gemv(const double* __restrict__ S, const double* __restrict__ w_re,
+                                                    const double* __restrict__ w_im, int B, int P, double* __restrict__ out) {
+    __shared__ double part[256];
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    double a = 0.0;
+    if (p < P)
+        for (int b = rg; b < B; b += 4) {
+            const double* s = S + ((size_t)b * P + p) * 2;
+            a += w_re[b] * s[0] + w_im[b] * s[1];
+        }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && p < P) out[p] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+}
+
 __global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) buf[i] *= s;
@@ -479,6 +495,7 @@ struct cg_ctx {
     size_t cur = 0, off = 0;
     // persistent workspace (derivative kernels)
     void* ws = nullptr; size_t ws_cap = 0;
+    double* d_scores = nullptr; size_t scores_cap = 0; int scores_B = 0;     // resident per-sample scores (cg_scores_*)
     std::string err;
 };
 
@@ -630,6 +647,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& ch : c->chunks) (void)hipFree(ch.p);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->d_scores) (void)hipFree(c->d_scores);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_spk) (void)hipFree(c->d_spk);
     if (c->d_tab) (void)hipFree(c->d_tab);
@@ -1021,7 +1039,8 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
 }
 
 static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
-                   const double* w_im, double* g_theta, double* score, double* fisher = nullptr, double* smean = nullptr) {
+                   const double* w_im, double* g_theta, double* score, double* fisher = nullptr, double* smean = nullptr,
+                   bool keep_scores = false) {
     int rc = check_ready(c, fn, B); if (rc) return rc;
     const int n = c->n, N = n * c->dim, P = c->P;
     if (B == 0) {
@@ -1041,9 +1060,14 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     Arg asm_{smean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
     Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc, &afi, &asm_};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    if (fisher && !asc.dev) {        // the scores of the Fisher matrix stay on the device
-        asc.dev = arena_take(c, asc.bytes);
-        if (!asc.dev) CG_FAIL(c, CG_ERR_HIP, "%s: %zu bytes for the per-sample scores could not be allocated", fn, asc.bytes);
+    if ((fisher || keep_scores) && !asc.dev) {        // the scores stay on the device, in the context's resident buffer
+        if (c->scores_cap < asc.bytes) {
+            if (c->d_scores) { CG_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_scores); c->d_scores = nullptr; c->scores_cap = 0; }
+            if (hipMalloc((void**)&c->d_scores, asc.bytes) != hipSuccess)
+                CG_FAIL(c, CG_ERR_HIP, "%s: %zu bytes for the per-sample scores could not be allocated", fn, asc.bytes);
+            c->scores_cap = asc.bytes;
+        }
+        asc.dev = c->d_scores; c->scores_B = B;
     }
     const int nt = 256;
     const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
@@ -1091,6 +1115,46 @@ int cg_param_vjp(cg_ctx* c, const double* x, const int32_t* sidx, int B, const d
 int cg_quantum_score(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* score) {
     if (c && !score) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_score: score is NULL");
     return run_vjp(c, "cg_quantum_score", x, sidx, B, nullptr, nullptr, nullptr, score);
+}
+/* Resident per-sample scores: computed once per (x, state_idx, theta), then reused for the theta-VJPs of the loss
+ * (weights 2 Re/Im E_clip / B and 2 / B, main.py:278) and for the Fisher matrix -- 2 reverse sweeps instead of 6. */
+int cg_scores_compute(cg_ctx* c, const double* x, const int32_t* sidx, int B) {
+    if (c && B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_scores_compute: empty batch");
+    return run_vjp(c, "cg_scores_compute", x, sidx, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+}
+int cg_scores_vjp(cg_ctx* c, const double* w_re, const double* w_im, double* g_theta) {
+    if (!c) return CG_ERR_ARG;
+    if (!c->d_scores || c->scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_scores_vjp: cg_scores_compute has not been called");
+    if (!w_re || !w_im || !g_theta) CG_FAIL(c, CG_ERR_ARG, "cg_scores_vjp: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->scores_B, P = c->P;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_scores_vjp: arena");
+    Arg awr{(void*)w_re, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg awi{(void*)w_im, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
+    Arg* all[] = {&awr, &awi, &ag};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    hipLaunchKernelGGL(k_score_gemv, dim3((P + 63) / 64), dim3(256), 0, c->stream, (const double*)c->d_scores, (const double*)awr.dev,
+                       (const double*)awi.dev, B, P, (double*)ag.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_scores_fisher(cg_ctx* c, double* fisher, double* score_mean) {
+    if (!c) return CG_ERR_ARG;
+    if (!c->d_scores || c->scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_scores_fisher: cg_scores_compute has not been called");
+    if (!fisher || !score_mean) CG_FAIL(c, CG_ERR_ARG, "cg_scores_fisher: NULL output");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->scores_B, P = c->P;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_scores_fisher: arena");
+    Arg afi{fisher, nullptr, sizeof(double) * (size_t)P * P, false, true};
+    Arg asm_{score_mean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
+    Arg* all[] = {&afi, &asm_};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int tiles = (P + 15) / 16;
+    hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)c->d_scores, B, P, (double*)afi.dev);
+    hipLaunchKernelGGL(k_score_mean, dim3((2 * P + 63) / 64), dim3(256), 0, c->stream, (const double*)c->d_scores, B, 2 * P, (double*)asm_.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
 }
 int cg_quantum_fisher(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* fisher, double* score_mean) {
     if (c && (!fisher || !score_mean)) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: NULL output");

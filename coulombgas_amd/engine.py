@@ -220,13 +220,32 @@ class Engine:
         lap = (l[:, 0] + 1j * l[:, 1]).reshape(lead)
         return grad, lap
 
-    def param_vjp(self, x, state_idx, w_re, w_im):
+    # Per-sample scores resident on the device (cg_scores_*): one score computation (two reverse sweeps) serves the two
+    # theta-VJPs of jax.jacrev(quantum_lossfn) (main.py:278) and the Fisher matrix of the SR optimizer, instead of one
+    # sweep (and one set-up) each.  Valid while (x, state_idx, theta) are unchanged.
+    SCORE_CACHE_MAX_BYTES = 4 << 30
+
+    def _scores_ready(self, xb, s):
+        B = xb.shape[0]
+        if B == 0 or B * self.P * 16 > self.SCORE_CACHE_MAX_BYTES:
+            return False
+        key = getattr(self, "_score_key", None)
+        if key is not None and key[2] is self._theta and key[0].shape == xb.shape and np.array_equal(key[0], xb) and np.array_equal(key[1], s):
+            return True
+        check(lib().cg_scores_compute(self._ctx, _p(xb), _p(s), B), self._ctx)
+        self._score_key = (xb.copy(), s.copy(), self._theta)
+        return True
+
+    def param_vjp(self, x, state_idx, w_re, w_im, use_scores=True):
         xb, _ = self._xb(x)
         B = xb.shape[0]
         s = self._sb(state_idx, B)
         w_re, w_im = _f64(w_re).reshape(B), _f64(w_im).reshape(B)
         g = np.empty(self.P)
-        check(lib().cg_param_vjp(self._ctx, _p(xb), _p(s), B, _p(w_re), _p(w_im), _p(g)), self._ctx)
+        if use_scores and self._mode == _lib.CG_PTR_HOST and self._scores_ready(xb, s):
+            check(lib().cg_scores_vjp(self._ctx, _p(w_re), _p(w_im), _p(g)), self._ctx)
+        else:
+            check(lib().cg_param_vjp(self._ctx, _p(xb), _p(s), B, _p(w_re), _p(w_im), _p(g)), self._ctx)
         return g
 
     def quantum_score(self, x, state_idx):
@@ -243,7 +262,10 @@ class Engine:
         B = xb.shape[0]
         s = self._sb(state_idx, B)
         F = np.empty((self.P, self.P)); sm = np.empty((self.P, 2))
-        check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
+        if self._mode == _lib.CG_PTR_HOST and self._scores_ready(xb, s):
+            check(lib().cg_scores_fisher(self._ctx, _p(F), _p(sm)), self._ctx)
+        else:
+            check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
         return F, sm[:, 0] + 1j * sm[:, 1]
 
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------

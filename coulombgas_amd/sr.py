@@ -43,9 +43,12 @@ def _ravel_batched(score):
 
 def _solve_and_clip(fisher, grads_raveled, damping, max_norm):
     """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1)."""
-    from scipy.linalg import solve
+    from scipy.linalg import solve, LinAlgError
     fisher = fisher + damping * np.eye(fisher.shape[0])
-    upd = solve(fisher, grads_raveled, assume_a="sym")
+    try:                                           # Fisher + damping I is symmetric positive definite: Cholesky
+        upd = solve(fisher, grads_raveled, assume_a="pos")
+    except LinAlgError:                            # (round-off made it indefinite: fall back to the symmetric solver)
+        upd = solve(fisher, grads_raveled, assume_a="sym")
     gnorm = float(np.sum(grads_raveled * upd))
     scale = min(np.sqrt(max_norm / gnorm), 1.0) if gnorm > 0 else 1.0
     return -scale * upd

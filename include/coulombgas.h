@@ -134,6 +134,12 @@ int cg_quantum_score(cg_ctx* ctx, const double* x, const int32_t* state_idx, int
 /* Quantum Fisher matrix and mean score of the hybrid SR optimizer, fishers_fn of src/sr.py:62-80 for ONE device (before
  * its pmean): fisher (P,P) = Re(S^H S) / B, score_mean (P,2) = mean_b S[b].  The scores stay on the device. */
 int cg_quantum_fisher(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, double* fisher, double* score_mean);
+/* The same in pieces, with the (B,P) score matrix resident on the device between the calls: one score computation (two
+ * reverse sweeps) then serves both theta-VJPs of jax.jacrev(quantum_lossfn) (main.py:278) and the Fisher matrix.
+ * cg_scores_vjp: g_theta (P) = sum_b w_re[b] Re S[b] + w_im[b] Im S[b]  (== cg_param_vjp on the same inputs). */
+int cg_scores_compute(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B);
+int cg_scores_vjp(cg_ctx* ctx, const double* w_re, const double* w_im, double* g_theta);
+int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
 

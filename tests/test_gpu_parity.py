@@ -220,7 +220,9 @@ def test_param_vjp_and_scores(case):
     w_re, w_im = rng.standard_normal(B), rng.standard_normal(B)
     eng = s["flow"].engine(n, dim, s["sp"])
     eng.set_params(s["theta"])
-    g = eng.param_vjp(s["x"], s["sidx"], w_re, w_im)
+    g = eng.param_vjp(s["x"], s["sidx"], w_re, w_im, use_scores=False)      # cg_param_vjp: one weighted reverse sweep
+    g2 = eng.param_vjp(s["x"], s["sidx"], w_re, w_im)                        # cg_scores_compute + cg_scores_vjp (resident scores)
+    assert np.abs(g2 - g).max() < 1e-11 * max(1.0, np.abs(g).max())
     r_logpsi = R.make_logpsi(s["rflow"], s["sp"], s["L"])
     sb = torch.as_tensor(s["sidx"].astype(np.int64))
     lpt = lambda xb, th, sbb: r_logpsi(xb, R.flow_unravel(th, 2, hs, ht, dim), sbb)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic: host wall time of each call of one SR epoch (main.py:316-346 mirror) at a BASELINE size."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import coulombgas_amd as cg
+from coulombgas_amd import sr as SR
+from tests.common import orbitals, box_length
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+L = box_length(n, 2); sp = orbitals(2, 25); rs = 10.0
+flow = cg.FermiNet(2, 16, 16, L); p0 = flow.init(1, np.zeros((n, 2)))
+samp = cg.GroundStateSampler(n, sp.shape[0])
+G = cg.kpoints(2, 15); Vconst = n * rs / L * cg.Madelung(2, 10, G)
+lp0 = cg.make_logpsi(flow, sp, L); logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L); logp = cg.make_logp(lp0)
+logpsi, lgl = cg.make_logpsi_grad_laplacian(lp0, hutchinson=True, logphi=logphi, logjacdet=logjac)
+loss = cg.make_loss(samp.log_prob, logpsi, lgl, 10, G, L, rs, Vconst, 1 / 0.6)
+fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(lp0), 1e-3, 1e-3)
+x = np.random.default_rng(0).uniform(0, L, (B, n, 2)); key = np.random.SeedSequence(1)
+T = {}
+def tm(name, fn):
+    t0 = time.perf_counter(); r = fn(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0; return r
+for ep in range(4):
+    if ep == 1: T.clear()
+    key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, None, logp, x, p0, 50, 0.1, L))
+    data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(None, p0, sidx, x, key))
+    g, s = tm("quantum grad (2 VJP)", lambda: qloss.grad(p0))
+    f = tm("fishers_fn", lambda: fishers_fn(None, p0, sidx, x))
+    gf = {k: {l: g[k][l] - data["E_mean"] * s[k][l] for l in g[k]} for k in g}
+    (uv, uf), _ = tm("SR solve+clip (host)", lambda: opt.update((None, gf), None, f))
+    p0 = tm("apply", lambda: cg.apply_updates(p0, uf))
+for k, v in T.items():
+    print("%-30s %7.1f ms" % (k, v / 3 * 1e3))
+print("%-30s %7.1f ms" % ("total", sum(T.values()) / 3 * 1e3))
