@@ -152,7 +152,8 @@ struct CgDerivs {
         const double* x = ws + w.x;
         for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
         b.sync();
-        F::primal(b, th, (const Jet2*)xj, n, L, ja, o);
+        CG_STAMP(0)
+        F::primal(b, th, (const Jet2*)xj, n, L, ja, o, nullptr, dir ? -1 : basis / D);   // basis pass: sparse tangent
         F::jacobian(b, th, n, L, ja, o);
     }
 
@@ -166,7 +167,8 @@ struct CgDerivs {
         const double* x = ws + w.x;
         for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], e == basis ? 1.0 : 0.0, 0.0);
         b.sync();
-        F::primal(b, th, (const Jet2*)xj, n, L, ja, o);
+        CG_STAMP(0)
+        F::primal(b, th, (const Jet2*)xj, n, L, ja, o, nullptr, basis / D);
         Dual* da2 = (Dual*)ja;
         const int cnt[4] = {N, N, n * HS, n * HS};
         const int off[4] = {o.sh, o.ch, o.sg1, o.sg2};
@@ -190,7 +192,9 @@ struct CgDerivs {
         const int N = n * D;
         const Ws& w = lay.w;
         const CgFastLds& o = lay.o;
+        CG_STAMP_START(20)
         setup(b, th, xg, spk, sidx, n, L, ws, w, o, true);
+        CG_STAMP_END(20)
         const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
         const double* gz = ws + w.gz; double* M = ws + w.M;
         const CgFastLds& oj = lay.oj;
@@ -199,6 +203,7 @@ struct CgDerivs {
         const int ndir = N + (mode == 0 ? 0 : 1);
         for (int dir = 0; dir < ndir; ++dir) {
             const bool probe = dir == N;
+            CG_STAMP_START(0)
             const bool split = !probe && mode == 2;        // only J' is needed: first-order Jacobian jets
             if (split) jet_pass_split(b, th, n, L, ws, w, oj, ja, (Jet2*)(ws + w.zs), dir);
             else jet_pass(b, th, n, L, ws, w, oj, ja, probe ? v : nullptr, dir);
@@ -261,6 +266,7 @@ struct CgDerivs {
             if (want_jac2) { t2 = cg_block_sum(b, t2, lds); t3 = cg_block_sum(b, t3, lds); lap_re += 0.5 * (t2 - t3); }
             if (!probe && b.tid == 0) { grad[2 * dir] = a_re + 0.5 * t1; grad[2 * dir + 1] = a_im; }
             b.sync();
+            CG_STAMP_END(8)
         }
         if (b.tid == 0) { lap[0] = lap_re; lap[1] = lap_im; }
     }

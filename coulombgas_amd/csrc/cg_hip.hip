@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(256, (JLDS ? (CG_DERIV_WAVES_OF(D) < 2 ? CG_DE
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     __syncthreads();
+    CG_STAMP_INIT
     const int n = m.n, N = n * D;
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
         CgDerivs<D, HS, HT>::grad_laplacian(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
@@ -205,6 +206,7 @@ __global__ void __launch_bounds__(256, (JLDS ? (CG_DERIV_WAVES_OF(D) < 2 ? CG_DE
                                             ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
         b.sync();
     }
+    CG_STAMP_FLUSH
 }
 
 template <int D, int HS, int HT>

@@ -88,3 +88,12 @@ CG_DEVI void cg_softplus_sigmoid(Dual u, Dual& sp, Dual& sg) {
 }
 CG_DEVI Dual cg_sigmoid(Dual u) { const double g = sigmoid_only(u.v); return {g, g * (1.0 - g) * u.d}; }
 CG_DEVI Dual cg_softplus(Dual u) { Dual s, g; cg_softplus_sigmoid(u, s, g); return s; }
+
+
+// value part / "carries derivatives" trait of the scalar types the flow code is instantiated with
+CG_DEVI double cg_val(double a) { return a; }
+CG_DEVI double cg_val(const Jet2& a) { return a.v; }
+CG_DEVI double cg_val(const Dual& a) { return a.v; }
+template <class T> struct CgIsJet { static constexpr bool value = false; };
+template <> struct CgIsJet<Jet2> { static constexpr bool value = true; };
+template <> struct CgIsJet<Dual> { static constexpr bool value = true; };
