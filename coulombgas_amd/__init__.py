@@ -11,10 +11,12 @@ from .mcmc import mcmc
 from .vmc import sample_stateindices_and_x, make_loss, make_observable
 from .sr import fisher_sr, hybrid_fisher_sr, apply_updates
 from .driver import train, make_update, adam, GroundStateSampler
+from .checkpoint import ckpt_filename, load_data, save_data, pretrained_model_filename
 from .utils import shard, replicate
 from .engine import Engine
 
 __all__ = ["FermiNet", "kpoints", "Madelung", "potential_energy", "make_logpsi", "make_logphi_logjacdet",
            "make_logpsi_grad_laplacian", "make_logp", "make_quantum_score", "mcmc",
            "sample_stateindices_and_x", "make_loss", "make_observable", "fisher_sr", "hybrid_fisher_sr", "apply_updates", "train", "make_update", "adam", "GroundStateSampler",
+           "ckpt_filename", "load_data", "save_data", "pretrained_model_filename",
            "shard", "replicate", "Engine"]
