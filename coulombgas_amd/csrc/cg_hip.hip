@@ -618,6 +618,13 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
         CG_FAST_CONFIGS(CG_X)
 #undef CG_X
         c->lay = cg_fast_layout(n, dim, spsize, tpsize, true, spsize == 16 && tpsize == 16);
+        // maximum size of the LDS-resident path: J (n d)^2 + the per-particle factors must fit 160 KiB.  Beyond it (n > ~64
+        // at d = 2) the same model runs on the general path (HBM workspace), which provides every entry point.
+        const size_t NN = (size_t)n * dim;
+        if (sizeof(double) * (CG_TAB_DOUBLES + (size_t)c->lay.total + 2 * ((NN + 1) & ~(size_t)1) + 2) > 160 * 1024) {
+            c->fast = false;
+            c->P = c->gm.nparam;
+        }
     }
     auto fail = [&](const char* what, hipError_t err) {
         g_last_error = std::string("cg_create: ") + what + ": " + hipGetErrorString(err);

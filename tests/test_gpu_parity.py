@@ -333,6 +333,33 @@ def test_large_n_against_c_oracle(n, Emax, B):
     assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
 
 
+def test_beyond_the_lds_limit_runs_on_the_general_path():
+    """Maximum size: at n = 72 (N = 144) J alone is 162 KB, more than the 160 KB of LDS; the same depth-2 model then runs
+    on the general path (HBM workspace) with identical results (C oracle) instead of failing."""
+    import ctypes as C
+    import coulombgas_amd as cg
+    from coulombgas_amd.build import build_oracle
+    lib = C.CDLL(build_oracle())
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    n, dim, B = 72, 2, 2
+    L = box_length(n, dim)
+    rng = np.random.default_rng(n)
+    sp = orbitals(2, 49)
+    theta = np.load(GOLDEN_DIR + "/shipped_n57_rs10.npz")["theta"]
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    eng = cg.FermiNet(2, 16, 16, L).engine(n, dim, sp)
+    eng.set_params(theta)
+    assert eng.launch_info()["fast"] == 0
+    out = np.zeros((B, 3))
+    lib.cgo_logpsi(n, dim, 2, 16, 16, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, p(out))
+    lphi, hld = eng.logphi_logjacdet(x, sidx)
+    assert np.abs(lphi[:, 0] - out[:, 0]).max() < 1e-10 * np.abs(out[:, 0]).max()
+    assert np.abs(np.angle(np.exp(1j * (lphi[:, 1] - out[:, 1])))).max() < 1e-10
+    assert np.abs(hld - out[:, 2]).max() < 1e-11
+    xg, lpg, nacc = eng.mcmc(x, sidx, 2, 0.1, seed=5)
+    assert np.isfinite(xg).all() and np.abs(lpg - eng.logp(xg, sidx)).max() < 1e-9 * np.abs(lpg).max()
+
+
 # ---------------------------------------------------------------------------------------------
 # general-depth path: the depth-3 networks of the reference's own tests (tests/test_flow.py:42, tests/test_logpsi.py:29)
 # ---------------------------------------------------------------------------------------------
