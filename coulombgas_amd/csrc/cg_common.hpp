@@ -268,3 +268,38 @@ CG_DEVI double cg_block_sum(const CgBlk& b, double v, double* scratch) {
     b.sync();
     return r;
 }
+
+// K sums at once: wave-level butterfly (no barrier), then the per-wave partials through LDS -- 2 barriers for all K
+// instead of ~10 per scalar cg_block_sum.  Fixed summation order (deterministic); every thread gets the totals.
+// scratch: >= K * (nthr / 64) doubles.  nthr must be a multiple of 64 on the GPU (1 on the host shim).
+template <int K>
+CG_DEVI void cg_block_sum_n(const CgBlk& b, double (&v)[K], double* scratch) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        v[k] = x;
+    }
+    const int nw = b.nthr >> 6;
+    if (nw > 1) {
+        const int wave = b.tid >> 6;
+        if ((b.tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) scratch[k * nw + wave] = v[k];
+        }
+        b.sync();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double a = 0.0;
+            for (int w = 0; w < nw; ++w) a += scratch[k * nw + w];
+            v[k] = a;
+        }
+        b.sync();
+    }
+#else
+    (void)b; (void)v; (void)scratch;
+#endif
+}
+

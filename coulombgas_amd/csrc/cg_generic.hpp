@@ -326,9 +326,13 @@ struct CgGenK {
                 b.sync();
                 for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, ga = e - al * N; t3 += M[al * N + ga] * M[ga * N + al]; }
             }
-            a_re = cg_block_sum(b, a_re, lds); a_im = cg_block_sum(b, a_im, lds); t1 = cg_block_sum(b, t1, lds);
-            if (want_phi2) { p_re = cg_block_sum(b, p_re, lds); p_im = cg_block_sum(b, p_im, lds); lap_re += p_re; lap_im += p_im; }
-            if (want_jac2) { t2 = cg_block_sum(b, t2, lds); t3 = cg_block_sum(b, t3, lds); lap_re += 0.5 * (t2 - t3); }
+            {   // the seven sums of this direction in one reduction (2 barriers)
+                double red[7] = {a_re, a_im, t1, p_re, p_im, t2, t3};
+                cg_block_sum_n<7>(b, red, lds);
+                a_re = red[0]; a_im = red[1]; t1 = red[2]; p_re = red[3]; p_im = red[4]; t2 = red[5]; t3 = red[6];
+            }
+            if (want_phi2) { lap_re += p_re; lap_im += p_im; }
+            if (want_jac2) lap_re += 0.5 * (t2 - t3);
             if (!probe && b.tid == 0) { grad[2 * dir] = a_re + 0.5 * t1; grad[2 * dir + 1] = a_im; }
             b.sync();
         }
