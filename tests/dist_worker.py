@@ -38,8 +38,13 @@ def main():
     logp = cg.make_logp(cg.make_logpsi(flow, pb["sp"], pb["L"]))
     key = np.random.SeedSequence(7).spawn(world)[rank]                      # jax.random.split(key, num_devices), main.py:237
     _, sidx, x, rate = cg.sample_stateindices_and_x(key, lambda pv, k, b: pb["sidx"][sl], None, logp, pb["x"][sl], pb["theta"], 4, 0.1, pb["L"])
+    # SR Fisher matrices: per-rank blocks all-reduced in fishers_fn (src/sr.py:70-76)
+    qscore = cg.make_quantum_score(cg.make_logpsi(flow, pb["sp"], pb["L"]))
+    cs_full = np.random.default_rng(99).standard_normal((pb["x"].shape[0], 5))
+    fishers_fn, _ = cg.hybrid_fisher_sr(lambda pv, si: cs_full[sl], qscore, 1e-3, 1e-3)
+    cf, qf, qm = fishers_fn(None, flow.unravel(pb["theta"], pb["x"].shape[-1]), pb["sidx"][sl], pb["x"][sl])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=np.array([obs[k] for k in sorted(obs)]), qv=np.array(qv), g=g, s=s,
-             rate=rate, x=x, tvE=float(np.abs(obs_fn.Eloc - obs["E_mean"]).mean()))
+             rate=rate, x=x, tvE=float(np.abs(obs_fn.Eloc - obs["E_mean"]).mean()), cf=cf, qf=qf, qm=qm)
     dist.barrier()
     dist.destroy_process_group()
 

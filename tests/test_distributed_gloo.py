@@ -21,7 +21,7 @@ def test_two_ranks_match_single_process(tmp_path, monkeypatch):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # every rank holds the same reduced values
-    for k in ("obs", "qv", "g", "s", "rate"):
+    for k in ("obs", "qv", "g", "s", "rate", "cf", "qf", "qm"):
         assert np.array_equal(r0[k], r1[k]), k
     assert not np.array_equal(r0["x"], r1["x"])                 # different walkers per rank
     # single process, full batch
@@ -39,3 +39,13 @@ def test_two_ranks_match_single_process(tmp_path, monkeypatch):
     assert np.abs(r0["g"] - g).max() < 1e-10 * max(1.0, np.abs(g).max())
     assert np.abs(r0["s"] - s).max() < 1e-11 * max(1.0, np.abs(s).max())
     assert 0.0 <= float(r0["rate"]) <= 1.0
+    # SR: mean over ranks of the per-rank Fisher blocks == Fisher matrix of the full batch (src/sr.py:70-76)
+    import coulombgas_amd as cg
+    flow = cg.FermiNet(2, 16, 16, pb["L"])
+    qscore = cg.make_quantum_score(cg.make_logpsi(flow, pb["sp"], pb["L"]))
+    cs_full = np.random.default_rng(99).standard_normal((pb["x"].shape[0], 5))
+    fishers_fn, _ = cg.hybrid_fisher_sr(lambda pv, si: cs_full, qscore, 1e-3, 1e-3)
+    cf, qf, qm = fishers_fn(None, flow.unravel(pb["theta"], pb["x"].shape[-1]), pb["sidx"], pb["x"])
+    assert np.abs(r0["cf"] - cf).max() < 1e-12 * np.abs(cf).max()
+    assert np.abs(r0["qf"] - qf).max() < 1e-10 * np.abs(qf).max() and np.abs(r0["qm"] - qm).max() < 1e-10 * np.abs(qm).max()
+
