@@ -859,9 +859,6 @@ struct CgFast {
             for (int h = 0; h < HS; ++h) v += (th[o_fw + h * D + a] * th[o_Wc + g * HS + h]) * sg2[i * HS + h];
             V[iV(i, a, g)] = v * rn;
         }
-#if defined(CG_JAC_STOP)
-        if (CG_JAC_STOP == 1) { b.sync(); return; }
-#endif
         // G pass: item (k,h)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;
@@ -892,9 +889,6 @@ struct CgFast {
         }
         b.sync();
         CG_STAMP(4)
-#if defined(CG_JAC_STOP)
-        if (CG_JAC_STOP == 2) return;
-#endif
         for (int e = b.tid; e < n * D * P; e += b.nthr) {      // U'_i: item (i,a,f)
             const int i = e / (D * P), r = e - i * (D * P), a = r / P, f = r - a * P;
             T v = T(0.0);
@@ -904,9 +898,6 @@ struct CgFast {
         }
         b.sync();
         CG_STAMP(5)
-#if defined(CG_JAC_STOP)
-        if (CG_JAC_STOP == 3) return;
-#endif
         // Jacobian pass: item (i,k), k != i
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, k = e - i * n;
