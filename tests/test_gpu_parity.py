@@ -484,3 +484,43 @@ def test_training_lowers_the_energy():
     E, Estd = v[:, 3], v[:, 4]
     assert np.isfinite(v).all() and (v[:, -1] > 0.2).all()
     assert np.median(E[-4:]) < E[0] - 4 * Estd[0], (E, Estd)
+
+
+def test_full_size_properties():
+    """BASELINE config 2/3 at full size (n=13, dim=2, 8192 walkers) through size-independent properties: lattice /
+    translation / permutation invariance of |Psi|^2 (tests/test_logpsi.py:45,54,72,77), block rows of J summing to the
+    identity (translation equivariance of the flow, tests/test_flow.py:32), the chain's bookkeeping, determinism, Ewald
+    invariances, linearity of the theta-VJP in its weights, and the score matrix reproducing the VJP."""
+    import coulombgas_amd as cg
+    n, dim, B = 13, 2, 8192
+    L = box_length(n, dim)
+    rng = np.random.default_rng(8192)
+    sp = orbitals(dim)
+    theta = flow_theta(rng, 2, 16, 16, dim, 0.2, 0.1)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, sp.shape[0])
+    eng = cg.FermiNet(2, 16, 16, L).engine(n, dim, sp); eng.set_params(theta)
+    lp = eng.logp(x, sidx)
+    assert np.isfinite(lp).all()
+    image = rng.integers(-3, 4, size=(B, n, dim)) * L
+    assert np.abs(eng.logp(x + image, sidx) - lp).max() < 1e-8 * np.abs(lp).max()
+    shift = rng.standard_normal((B, 1, dim))
+    assert np.abs(eng.logp(x + shift, sidx) - lp).max() < 1e-8 * np.abs(lp).max()
+    perm = rng.permutation(n)
+    assert np.abs(eng.logp(x[:, perm], sidx) - lp).max() < 1e-8 * np.abs(lp).max()
+    J = eng.flow_jacobian(x[:512]).reshape(512, n, dim, n, dim)
+    assert np.abs(J.sum(axis=3) - np.eye(dim)).max() < 1e-12
+    x1, lp1, na1 = eng.mcmc(x, sidx, 10, 0.1, seed=77)
+    x2, lp2, na2 = eng.mcmc(x, sidx, 10, 0.1, seed=77)
+    assert np.array_equal(x1, x2) and np.array_equal(lp1, lp2) and na1 == na2 and 0.3 < na1 / (10 * B) < 0.9
+    assert np.abs(lp1 - eng.logp(x1, sidx)).max() < 1e-9 * np.abs(lp1).max()
+    eng.set_ewald(10, cg.kpoints(dim, 15), 10.0)
+    V = eng.ewald(x)
+    assert np.abs(eng.ewald(x + image) - V).max() < 1e-9 * np.abs(V).max() and np.abs(eng.ewald(x[:, perm]) - V).max() < 1e-10 * np.abs(V).max()
+    w1, w2, w3, w4 = (rng.standard_normal(B) for _ in range(4))
+    ga = eng.param_vjp(x, sidx, w1, w2, use_scores=False); gb = eng.param_vjp(x, sidx, w3, w4, use_scores=False)
+    gc = eng.param_vjp(x, sidx, 2.0 * w1 - w3, 2.0 * w2 - w4, use_scores=False)
+    assert np.abs(gc - (2.0 * ga - gb)).max() < 1e-9 * np.abs(ga).max()
+    assert np.abs(eng.param_vjp(x, sidx, w1, w2) - ga).max() < 1e-9 * np.abs(ga).max()      # from the resident score matrix
+    F, sm = eng.quantum_fisher(x, sidx)
+    assert np.abs(F - F.T).max() == 0.0 and np.linalg.eigvalsh(F).min() > -1e-9 * np.abs(F).max()
+    assert np.abs(eng.param_vjp(x, sidx, np.full(B, 1.0 / B), np.zeros(B)) - sm.real).max() < 1e-10 * np.abs(sm).max()
