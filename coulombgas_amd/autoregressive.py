@@ -1,0 +1,124 @@
+"""Host-side (numpy) forward pass of the autoregressive Transformer of src/autoregressive.py and the sampler /
+log-probability of src/sampler.py.  It produces the integer `state_indices` the accelerated hot path consumes and the
+entropy term log p of the loss; it is n tiny batched matmuls per sampling call and stays on the host.
+
+Forward only: training params_van needs its gradients (jax.grad(log_prob), src/sampler.py:65), which the caller still
+supplies (`log_prob_vjp`, `classical_score_fn` of coulombgas_amd.driver / .sr).  Parameters keep Haiku's names and
+shapes, so shipped `params_van` (checkpoints, pretrained models) load unchanged."""
+import numpy as np
+
+
+def _linear(p, x):
+    return x @ p["w"] + p["b"]
+
+
+class Transformer:
+    """src/autoregressive.py:50-96.  apply(params, None, x): x (..., n, dim) -> logits (..., n, output_size)."""
+
+    def __init__(self, output_size, num_layers, model_size, num_heads, hidden_size, name="transformer"):
+        if model_size % num_heads != 0:
+            raise ValueError("Model_size of the transformer must be divisible by the number of heads. "
+                             "Got model_size=%d and num_heads=%d." % (model_size, num_heads))
+        self.output_size, self.num_layers, self.model_size, self.num_heads = output_size, num_layers, model_size, num_heads
+        self.key_size = model_size // num_heads
+        self.hidden_size, self.name = hidden_size, name
+
+    # -- parameters ------------------------------------------------------------------------------------------
+    def param_shapes(self, dim):
+        nm, ms, hs = self.name, self.model_size, self.hidden_size
+        shapes = {nm: {"x1hat": (self.output_size,)}, nm + "/embedding_mlp": {"b": (ms,), "w": (dim, ms)},
+                  nm + "/output_mlp": {"b": (self.output_size,), "w": (ms, self.output_size)}}
+        for i in range(self.num_layers):
+            for part in ("query", "key", "value", "linear"):
+                shapes["%s/layer%d_attn/%s" % (nm, i, part)] = {"b": (ms,), "w": (ms, ms)}
+            shapes["%s/layer%d_mlp/linear" % (nm, i)] = {"b": (hs,), "w": (ms, hs)}
+            shapes["%s/layer%d_mlp/linear_1" % (nm, i)] = {"b": (ms,), "w": (hs, ms)}
+        return shapes
+
+    def init(self, key, x):
+        """hk.transform(...).init: VarianceScaling(0.02 / num_layers) weights (fan_in, truncated normal), zero biases,
+        x1hat ~ TruncatedNormal(sqrt(init_scale / output_size)) (src/autoregressive.py:72-93)."""
+        rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+        dim = np.shape(x)[-1]
+        scale = 0.02 / self.num_layers
+
+        def trunc(shape, std):
+            v = rng.standard_normal(shape)
+            bad = np.abs(v) > 2.0
+            while bad.any():
+                v[bad] = rng.standard_normal(int(bad.sum())); bad = np.abs(v) > 2.0
+            return v * std
+        out = {}
+        for mod, leaves in self.param_shapes(dim).items():
+            out[mod] = {}
+            for leaf, shp in leaves.items():
+                if leaf == "b":
+                    out[mod][leaf] = np.zeros(shp)
+                elif leaf == "x1hat":
+                    out[mod][leaf] = trunc(shp, np.sqrt(scale / self.output_size))
+                else:
+                    fan = shp[1] if mod.endswith("embedding_mlp") else shp[0]      # "fan_out" for the embedding (:75)
+                    out[mod][leaf] = trunc(shp, np.sqrt(scale / fan) / 0.87962566103423978)
+        return out
+
+    # -- forward ---------------------------------------------------------------------------------------------
+    def _attention(self, params, i, x):
+        nm = "%s/layer%d_attn/" % (self.name, i)
+        T = x.shape[-2]
+        H, K = self.num_heads, self.key_size
+        split = lambda y: y.reshape(y.shape[:-1] + (H, K))
+        q, k, v = (split(_linear(params[nm + part], x)) for part in ("query", "key", "value"))
+        logits = np.einsum("...thd,...Thd->...htT", q, k) / np.sqrt(K)
+        mask = np.tril(np.ones((T, T), dtype=bool))                                # CausalSelfAttention, :26-27
+        logits = np.where(mask, logits, -1e30)
+        logits = logits - logits.max(axis=-1, keepdims=True)
+        w = np.exp(logits); w /= w.sum(axis=-1, keepdims=True)
+        attn = np.einsum("...htT,...Thd->...thd", w, v)
+        return _linear(params[nm + "linear"], attn.reshape(attn.shape[:-2] + (H * K,)))
+
+    def apply(self, params, rng, x):
+        nm = self.name
+        x = np.tanh(_linear(params[nm + "/embedding_mlp"], np.asarray(x, dtype=np.float64)))
+        for i in range(self.num_layers):
+            x = x + self._attention(params, i, x)
+            h = np.tanh(_linear(params["%s/layer%d_mlp/linear" % (nm, i)], x))
+            x = x + _linear(params["%s/layer%d_mlp/linear_1" % (nm, i)], h)
+        x = _linear(params[nm + "/output_mlp"], np.tanh(x))
+        x1hat = np.broadcast_to(params[nm]["x1hat"], x.shape[:-2] + (1, self.output_size))
+        return np.concatenate([x1hat, x[..., :-1, :]], axis=-2)                    # :93
+
+
+def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False):
+    """src/sampler.py:4-50 with a leading batch axis built in (the reference vmaps).  sampler(params, key, batch) ->
+    (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,)."""
+    sp_indices = np.asarray(sp_indices, dtype=np.float64)
+    base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
+
+    def _mask(state_idx):
+        state_idx = np.asarray(state_idx)
+        idx_lb = np.concatenate([np.full(state_idx.shape[:-1] + (1,), -1), state_idx[..., :-1]], axis=-1)
+        return base & (np.arange(num_states) > idx_lb[..., None])
+
+    def _logits(params, state_idx):
+        logits = network.apply(params, None, sp_indices[state_idx])
+        return np.where(_mask(state_idx), logits, -1e50)
+
+    def sampler(params, key, batch):
+        rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+        state_indices = np.zeros((batch, n), dtype=np.int32)
+        for i in range(n):
+            logits = _logits(params, state_indices)[:, i, :]
+            g = -np.log(-np.log(rng.uniform(size=logits.shape)))                   # Gumbel-max = jax.random.categorical
+            state_indices[:, i] = np.argmax(logits + g, axis=-1)
+        return state_indices
+
+    def log_prob(params, state_idx):
+        state_idx = np.asarray(state_idx)
+        logits = _logits(params, state_idx)
+        m = logits.max(axis=-1, keepdims=True)
+        logp = logits - m - np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
+        return np.take_along_axis(logp, state_idx[..., None], axis=-1)[..., 0].sum(axis=-1)
+
+    if mask_fn:
+        return _mask, sampler, log_prob
+    return sampler, log_prob

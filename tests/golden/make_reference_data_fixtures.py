@@ -83,7 +83,21 @@ def shipped(n, rs, epoch, nwalk, out):
     print(out, x[:nwalk].shape, theta.shape, row)
 
 
+def van_fixture(src_pkl, key, out, extra):
+    """params_van of a shipped model (pretrained free-fermion model or a checkpoint) as flat npz: 'module|leaf' -> array."""
+    ck = _Unpickler(open(src_pkl, "rb")).load()
+    pv = ck if key is None else ck[key]
+    flat = {"%s|%s" % (m, l): np.asarray(v) for m in pv for l, v in pv[m].items()}
+    np.savez_compressed(os.path.join(HERE, out), **flat, **extra)
+    print(out, len(flat), "leaves")
+
+
 if __name__ == "__main__":
+    d = glob.glob("%s/data/freefermion/pretraining/n_13_*/*" % REF)[0]
+    van_fixture(os.path.join(d, "params_van.pkl"), None, "pretrained_van_n13.npz",
+                {"data_row_last": np.loadtxt(os.path.join(d, "data.txt"))[-1]})
+    d = glob.glob("%s/data/n_29_dim_2_rs_10.0_*" % REF)[0]
+    van_fixture(os.path.join(d, "epoch_003000.pkl"), "params_van", "shipped_n29_rs10_van.npz", {})
     for Emax in (25, 36, 49):
         t = twisted_table(2, Emax, (0.25, 0.25))
         np.save(os.path.join(HERE, "orbitals_dim2_Emax%d.npy" % Emax), t)

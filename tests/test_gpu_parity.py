@@ -524,3 +524,44 @@ def test_full_size_properties():
     F, sm = eng.quantum_fisher(x, sidx)
     assert np.abs(F - F.T).max() == 0.0 and np.linalg.eigvalsh(F).min() > -1e-9 * np.abs(F).max()
     assert np.abs(eng.param_vjp(x, sidx, np.full(B, 1.0 / B), np.zeros(B)) - sm.real).max() < 1e-10 * np.abs(sm).max()
+
+
+def test_shipped_model_reproduces_published_energies():
+    """Statistical end-to-end KAT with the shipped n=29, rs=10 epoch-3000 models (Transformer density matrix + trained flow):
+    host sampler -> GPU Metropolis chains -> GPU local energies reproduce the E and F of the published data.txt row
+    (agreement within ~0.15 %; K and V separately are only loose, App. B6)."""
+    import coulombgas_amd as cg
+    n, dim, rs, Theta = 29, 2, 10.0, 0.15
+    L, beta = box_length(n, dim), 1 / (4 * 0.15)
+    sp = orbitals(2, 25)
+    fix = np.load(GOLDEN_DIR + "/shipped_n29_rs10.npz")
+    z = np.load(GOLDEN_DIR + "/shipped_n29_rs10_van.npz")
+    pv = {}
+    for k in z.files:
+        m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0])
+    flow = cg.FermiNet(2, 16, 16, L)
+    pf = flow.unravel(fix["theta"], dim)
+    logpsi0 = cg.make_logpsi(flow, sp, L)
+    logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L)
+    logp = cg.make_logp(logpsi0)
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi0, hutchinson=True, logphi=logphi, logjacdet=logjac)
+    G = cg.kpoints(dim, 15)
+    Vconst = n * rs / L * cg.Madelung(dim, 10, G)
+    loss = cg.make_loss(log_prob, logpsi, lgl, 10, G, L, rs, Vconst, beta)
+    B = 512
+    x = fix["x"][:B].copy()                                        # shipped (already thermalised) walkers
+    key = np.random.SeedSequence(5)
+    E, F = [], []
+    for it in range(6):
+        key, sidx, x, acc = cg.sample_stateindices_and_x(key, sampler, pv, logp, x, pf, 50, 0.1, L)
+        if it >= 2:
+            obs, _, _ = loss(pv, pf, sidx, x, key)
+            E.append(obs["E_mean"] / rs ** 2); F.append(obs["F_mean"] / rs ** 2)
+    row = fix["data_row"]                                          # epoch F F_std E E_std K K_std V V_std S S_std accept
+    print("shipped n=29 rs=10: E %.4f (published %.4f)  F %.4f (published %.4f)  accept %.3f (published %.3f)"
+          % (np.mean(E), row[3], np.mean(F), row[1], acc, row[11]))
+    assert 0.3 < acc < 0.6
+    assert abs(np.mean(E) - row[3]) < 0.01 * abs(row[3]), (np.mean(E), row[3])
+    assert abs(np.mean(F) - row[1]) < 0.01 * abs(row[1]), (np.mean(F), row[1])

@@ -249,3 +249,47 @@ def test_checkpoint_interop(tmp_path):
         fix = np.load(GOLDEN + "/shipped_n29_rs10.npz")
         th = np.concatenate([np.asarray(c["params_flow"][k][l]).ravel() for k in sorted(c["params_flow"]) for l in ("b", "w")])
         assert np.array_equal(th, fix["theta"]) and np.array_equal(c["x"].reshape(-1, 29, 2)[:512], fix["x"])
+
+
+def _load_van(name):
+    z = np.load(GOLDEN + "/" + name)
+    pv = {}
+    for k in z.files:
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    return pv, z
+
+
+def test_autoregressive_sampler_kats():
+    """src/autoregressive.py + src/sampler.py (numpy forward): (i) tests/test_sampler.py:40-69 -- the conditional
+    probabilities sum to one over all C(10,4) ordered occupations; (ii) the mask of src/sampler.py:72-91; (iii) the
+    shipped pretrained free-fermion model (n=13): F = <log p / beta + E> reproduces the published value of its data.txt."""
+    import itertools
+    sp10 = orbitals(2)[-10:]
+    van = cg.Transformer(10, 2, 16, 4, 32)
+    params = van.init(0, sp10[:4])
+    mask_fn, sampler, log_prob = cg.make_autoregressive_sampler(van, sp10, 4, 10, mask_fn=True)
+    si = np.array(list(itertools.combinations(range(10), 4)))
+    assert np.exp(log_prob(params, si)).sum() == pytest.approx(1.0, abs=1e-12)
+    m = mask_fn(np.array([1, 4, 5, 7])).astype(int)
+    assert m.tolist() == [[1, 1, 1, 1, 1, 1, 1, 0, 0, 0], [0, 0, 1, 1, 1, 1, 1, 1, 0, 0], [0, 0, 0, 0, 0, 1, 1, 1, 1, 0], [0, 0, 0, 0, 0, 0, 1, 1, 1, 1]]
+    s = sampler(params, 3, 64)
+    assert s.shape == (64, 4) and (np.diff(s, axis=1) > 0).all() and s.min() >= 0 and s.max() < 10
+    with pytest.raises(ValueError):
+        cg.Transformer(10, 2, 16, 3, 32)
+    # shipped pretrained model
+    pv, z = _load_van("pretrained_van_n13.npz")
+    n, Theta = 13, 0.15
+    L, beta = np.sqrt(np.pi * n), 1 / (4 * Theta)
+    spt = orbitals(2, 25)
+    Es = (2 * np.pi / L) ** 2 * (spt ** 2).sum(-1)                                    # src/freefermion/pretraining.py:54
+    van = cg.Transformer(spt.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, spt, n, spt.shape[0])
+    B = 4096
+    s = sampler(pv, 1, B)
+    lp = log_prob(pv, s)
+    F = lp / beta + Es[s].sum(-1)
+    row = z["data_row_last"]                                                          # epoch, F, F_std, E, E_std, S, S_std
+    assert abs(F.mean() - row[1]) < 5 * np.hypot(F.std() / np.sqrt(B), row[2])
+    assert abs(Es[s].sum(-1).mean() - row[3]) < 5 * np.hypot(Es[s].sum(-1).std() / np.sqrt(B), row[4])
+    assert abs(-lp.mean() - row[5]) < 5 * np.hypot(lp.std() / np.sqrt(B), row[6])
