@@ -2,8 +2,8 @@
 
 Exports the names main.py takes from the reference's `src` package for this path
 (src/__init__.py:1-13) plus the SR optimizer (src/sr.py); the checkpoint format and a host-side forward pass of the
-autoregressive Transformer sampler (src/autoregressive.py, src/sampler.py); its training and the free-fermion
-pre-training stay outside."""
+autoregressive Transformer sampler (src/autoregressive.py, src/sampler.py); with its gradients, and the free-fermion
+pre-training (src/freefermion/pretraining.py)."""
 from .flow import FermiNet
 from .potential import kpoints, Madelung, potential_energy
 from .logpsi import (make_logpsi, make_logphi_logjacdet, make_logpsi_grad_laplacian, make_logp,
@@ -13,12 +13,13 @@ from .vmc import sample_stateindices_and_x, make_loss, make_observable
 from .sr import fisher_sr, hybrid_fisher_sr, apply_updates
 from .driver import train, make_update, adam, GroundStateSampler
 from .checkpoint import ckpt_filename, load_data, save_data, pretrained_model_filename
-from .autoregressive import Transformer, make_autoregressive_sampler
+from .autoregressive import Transformer, make_autoregressive_sampler, make_classical_score
+from .freefermion import pretrain, exact_free_energy
 from .utils import shard, replicate
 from .engine import Engine
 
 __all__ = ["FermiNet", "kpoints", "Madelung", "potential_energy", "make_logpsi", "make_logphi_logjacdet",
            "make_logpsi_grad_laplacian", "make_logp", "make_quantum_score", "mcmc",
            "sample_stateindices_and_x", "make_loss", "make_observable", "fisher_sr", "hybrid_fisher_sr", "apply_updates", "train", "make_update", "adam", "GroundStateSampler",
-           "ckpt_filename", "load_data", "save_data", "pretrained_model_filename", "Transformer", "make_autoregressive_sampler",
+           "ckpt_filename", "load_data", "save_data", "pretrained_model_filename", "Transformer", "make_autoregressive_sampler", "make_classical_score", "pretrain", "exact_free_energy",
            "shard", "replicate", "Engine"]

@@ -2,9 +2,10 @@
 log-probability of src/sampler.py.  It produces the integer `state_indices` the accelerated hot path consumes and the
 entropy term log p of the loss; it is n tiny batched matmuls per sampling call and stays on the host.
 
-Forward only: training params_van needs its gradients (jax.grad(log_prob), src/sampler.py:65), which the caller still
-supplies (`log_prob_vjp`, `classical_score_fn` of coulombgas_amd.driver / .sr).  Parameters keep Haiku's names and
-shapes, so shipped `params_van` (checkpoints, pretrained models) load unchanged."""
+Gradients of log p w.r.t. the parameters (jax.grad(log_prob), src/sampler.py:65: the classical score of the SR optimizer
+and the VJP jax.jacrev(classical_lossfn) needs) come from a hand-written reverse pass of the same forward code
+(`log_prob.grad` / `log_prob.vjp` / `make_classical_score`).  Parameters keep Haiku's names and shapes, so shipped
+`params_van` (checkpoints, pretrained models) load unchanged."""
 import numpy as np
 
 
@@ -76,6 +77,71 @@ class Transformer:
         attn = np.einsum("...htT,...Thd->...thd", w, v)
         return _linear(params[nm + "linear"], attn.reshape(attn.shape[:-2] + (H * K,)))
 
+    def forward_cache(self, params, x):
+        """apply() keeping what the reverse pass needs.  x (B, T, dim)."""
+        nm, H, K = self.name, self.num_heads, self.key_size
+        x0 = np.asarray(x, dtype=np.float64)
+        T = x0.shape[-2]
+        h = np.tanh(_linear(params[nm + "/embedding_mlp"], x0))
+        cache = {"x0": x0, "h0": h, "layers": []}
+        mask = np.tril(np.ones((T, T), dtype=bool))
+        for i in range(self.num_layers):
+            an = "%s/layer%d_attn/" % (nm, i)
+            split = lambda y: y.reshape(y.shape[:-1] + (H, K))
+            q, k, v = (split(_linear(params[an + part], h)) for part in ("query", "key", "value"))
+            lg = np.where(mask, np.einsum("bthd,bThd->bhtT", q, k) / np.sqrt(K), -1e30)
+            lg = lg - lg.max(axis=-1, keepdims=True)
+            A = np.exp(lg); A /= A.sum(axis=-1, keepdims=True)
+            o = np.einsum("bhtT,bThd->bthd", A, v).reshape(h.shape[:-1] + (H * K,))
+            h1 = h + _linear(params[an + "linear"], o)
+            m = np.tanh(_linear(params["%s/layer%d_mlp/linear" % (nm, i)], h1))
+            h2 = h1 + _linear(params["%s/layer%d_mlp/linear_1" % (nm, i)], m)
+            cache["layers"].append({"hin": h, "q": q, "k": k, "v": v, "A": A, "o": o, "h1": h1, "m": m})
+            h = h2
+        th = np.tanh(h)
+        y = _linear(params[nm + "/output_mlp"], th)
+        cache["th"] = th
+        x1hat = np.broadcast_to(params[nm]["x1hat"], y.shape[:-2] + (1, self.output_size))
+        return np.concatenate([x1hat, y[..., :-1, :]], axis=-2), cache
+
+    def backward(self, params, cache, dlogits, per_sample):
+        """Reverse pass: dlogits (B, T, output_size) -> parameter gradients, with a leading batch axis on every leaf when
+        per_sample, otherwise summed over the batch."""
+        nm, H, K = self.name, self.num_heads, self.key_size
+        B, T = dlogits.shape[0], dlogits.shape[1]
+        wsum = (lambda a, d: np.einsum("bti,bto->bio", a, d)) if per_sample else (lambda a, d: np.einsum("bti,bto->io", a, d))
+        bsum = (lambda d: d.sum(axis=1)) if per_sample else (lambda d: d.sum(axis=(0, 1)))
+        g = {nm: {"x1hat": dlogits[:, 0, :] if per_sample else dlogits[:, 0, :].sum(axis=0)}}
+        dy = np.concatenate([dlogits[:, 1:, :], np.zeros((B, 1, self.output_size))], axis=1)
+        po = params[nm + "/output_mlp"]
+        g[nm + "/output_mlp"] = {"w": wsum(cache["th"], dy), "b": bsum(dy)}
+        dh = (dy @ po["w"].T) * (1.0 - cache["th"] ** 2)
+        for i in reversed(range(self.num_layers)):
+            c = cache["layers"][i]
+            an = "%s/layer%d_attn/" % (nm, i)
+            p1, p2 = params["%s/layer%d_mlp/linear" % (nm, i)], params["%s/layer%d_mlp/linear_1" % (nm, i)]
+            g["%s/layer%d_mlp/linear_1" % (nm, i)] = {"w": wsum(c["m"], dh), "b": bsum(dh)}
+            dpre = (dh @ p2["w"].T) * (1.0 - c["m"] ** 2)
+            g["%s/layer%d_mlp/linear" % (nm, i)] = {"w": wsum(c["h1"], dpre), "b": bsum(dpre)}
+            dh1 = dh + dpre @ p1["w"].T
+            pl = params[an + "linear"]
+            g[an + "linear"] = {"w": wsum(c["o"], dh1), "b": bsum(dh1)}
+            do = (dh1 @ pl["w"].T).reshape(B, T, H, K)
+            dA = np.einsum("bthd,bThd->bhtT", do, c["v"])
+            dv = np.einsum("bhtT,bthd->bThd", c["A"], do)
+            dS = c["A"] * (dA - (c["A"] * dA).sum(axis=-1, keepdims=True)) / np.sqrt(K)
+            dq = np.einsum("bhtT,bThd->bthd", dS, c["k"]).reshape(B, T, H * K)
+            dk = np.einsum("bhtT,bthd->bThd", dS, c["q"]).reshape(B, T, H * K)
+            dv = dv.reshape(B, T, H * K)
+            dhin = dh1
+            for part, d in (("query", dq), ("key", dk), ("value", dv)):
+                g[an + part] = {"w": wsum(c["hin"], d), "b": bsum(d)}
+                dhin = dhin + d @ params[an + part]["w"].T
+            dh = dhin
+        dpre0 = dh * (1.0 - cache["h0"] ** 2)
+        g[nm + "/embedding_mlp"] = {"w": wsum(cache["x0"], dpre0), "b": bsum(dpre0)}
+        return g
+
     def apply(self, params, rng, x):
         nm = self.name
         x = np.tanh(_linear(params[nm + "/embedding_mlp"], np.asarray(x, dtype=np.float64)))
@@ -119,6 +185,32 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         logp = logits - m - np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
         return np.take_along_axis(logp, state_idx[..., None], axis=-1)[..., 0].sum(axis=-1)
 
+    def _dlogits(params, state_idx):
+        state_idx = np.asarray(state_idx)
+        logits, cache = network.forward_cache(params, sp_indices[state_idx])
+        logits = np.where(_mask(state_idx), logits, -1e50)
+        m = logits.max(axis=-1, keepdims=True)
+        p = np.exp(logits - m); p /= p.sum(axis=-1, keepdims=True)
+        d = -p
+        np.put_along_axis(d, state_idx[..., None], np.take_along_axis(d, state_idx[..., None], axis=-1) + 1.0, axis=-1)
+        return d, cache                                       # d log p / d logits = onehot - softmax (0 on masked entries)
+
+    def grad(params, state_idx):
+        """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients, every leaf with a leading batch axis."""
+        d, cache = _dlogits(params, state_idx)
+        return network.backward(params, cache, d, per_sample=True)
+
+    def vjp(params, state_idx, w):
+        """sum_b w[b] * d log_prob_b / d params  (what jax.jacrev of a weighted sum of log-probabilities returns)."""
+        d, cache = _dlogits(params, state_idx)
+        return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)
+
+    log_prob.grad, log_prob.vjp = grad, vjp
     if mask_fn:
         return _mask, sampler, log_prob
     return sampler, log_prob
+
+
+def make_classical_score(log_prob):
+    """src/sampler.py:52-65: params, (batch, n) samples -> pytree of per-sample scores d log p / d params."""
+    return lambda params, state_indices: log_prob.grad(params, state_indices)

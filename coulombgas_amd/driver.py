@@ -4,10 +4,10 @@
 algebra grad - <F> score / grad - <E> score, optimizer step); `train` mirrors the epoch loop (:316-384) including the
 thermalisation rounds (:241-246) and the data.txt row format (:367-372).
 
-The variational density matrix (autoregressive Transformer, src/autoregressive.py + src/sampler.py) is outside the
-accelerated path: the caller passes `sampler`, `log_prob` and -- if params_van is to be trained -- `log_prob_vjp`
-(the vector-Jacobian product jax.jacrev(classical_lossfn) needs) and `classical_score_fn`.  `GroundStateSampler`
-is the trivial stand-in (zero temperature: every walker in the n lowest orbitals, log_prob = 0)."""
+The variational density matrix is passed as `sampler`, `log_prob` (+ `log_prob_vjp`, the vector-Jacobian product
+jax.jacrev(classical_lossfn) needs, and `classical_score_fn` if params_van is to be trained).  With
+coulombgas_amd.make_autoregressive_sampler (the reference's Transformer, host numpy) all four come from one object.
+`GroundStateSampler` is the trivial stand-in (zero temperature: every walker in the n lowest orbitals, log_prob = 0)."""
 import numpy as np
 from . import sr as _sr
 from .comm import get_comm
@@ -131,6 +131,10 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
     """main.py:216-384 on one rank.  sr = (damping, max_norm) selects hybrid_fisher_sr (main.py:179-184), otherwise
     `optimizer` (default adam(1e-3)).  Returns (params_van, params_flow, rows) with rows the data.txt lines."""
     cm = comm or get_comm()
+    if log_prob_vjp is None and hasattr(log_prob, "vjp"):          # make_autoregressive_sampler's log_prob carries its own
+        log_prob_vjp = log_prob.vjp                                 # reverse pass: the density matrix is trained as well
+        if classical_score_fn is None and hasattr(log_prob, "grad"):
+            classical_score_fn = log_prob.grad
     G = kpoints(dim, Gmax)
     Vconst = n * rs / L * Madelung(dim, kappa, G)                                      # :170-171
     logpsi_novmap = make_logpsi(flow, sp_indices, L)

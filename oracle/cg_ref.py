@@ -419,3 +419,40 @@ def hybrid_fisher_sr_update(classical_score, quantum_score, grad_van, grad_flow,
     return (classical_fisher, quantum_fisher, quantum_score_mean,
             sr_solve_and_clip(classical_fisher, grad_van, damping, max_norm),
             sr_solve_and_clip(qf, grad_flow, damping, max_norm))
+
+
+# --------------------------------------------------------------------------- #
+# src/autoregressive.py + src/sampler.py (torch restatement: autograd gives the checker's gradients)
+# --------------------------------------------------------------------------- #
+def transformer_apply(params, x, num_layers, num_heads):
+    """src/autoregressive.py:70-96 for one sample x (n, dim); params: dict module -> leaf -> torch tensor."""
+    nm = "transformer"
+    lin = lambda p, y: y @ p["w"] + p["b"]
+    x = torch.tanh(lin(params[nm + "/embedding_mlp"], x))
+    T = x.shape[0]
+    mask = torch.tril(torch.ones((T, T)))[None]
+    for i in range(num_layers):
+        an = "%s/layer%d_attn/" % (nm, i)
+        ms = x.shape[-1]; K = ms // num_heads
+        q, k, v = (lin(params[an + part], x).reshape(T, num_heads, K) for part in ("query", "key", "value"))
+        lg = torch.einsum("thd,Thd->htT", q, k) / np.sqrt(K)
+        lg = torch.where(mask > 0, lg, torch.tensor(-1e30, dtype=lg.dtype))
+        w = torch.softmax(lg, dim=-1)
+        o = torch.einsum("htT,Thd->thd", w, v).reshape(T, ms)
+        x = x + lin(params[an + "linear"], o)
+        h = torch.tanh(lin(params["%s/layer%d_mlp/linear" % (nm, i)], x))
+        x = x + lin(params["%s/layer%d_mlp/linear_1" % (nm, i)], h)
+    x = lin(params[nm + "/output_mlp"], torch.tanh(x))
+    return torch.vstack((params[nm]["x1hat"][None], x[:-1]))
+
+
+def autoregressive_log_prob(params, state_idx, sp_indices, num_layers, num_heads):
+    """src/sampler.py:6-46 for one sample (state_idx (n,) int64)."""
+    n, num_states = state_idx.shape[0], sp_indices.shape[0]
+    logits = transformer_apply(params, sp_indices[state_idx], num_layers, num_heads)
+    mask = torch.tril(torch.ones((n, num_states)), diagonal=num_states - n)
+    idx_lb = torch.cat((torch.tensor([-1]), state_idx[:-1]))
+    mask = torch.where(torch.arange(num_states) > idx_lb[:, None], mask, torch.zeros(()))
+    logits = torch.where(mask > 0, logits, torch.tensor(-1e50, dtype=logits.dtype))
+    logp = torch.log_softmax(logits, dim=-1)
+    return logp[torch.arange(n), state_idx].sum()

@@ -194,6 +194,18 @@ def test_training_loop_runs_and_logs(monkeypatch):
         assert vals[9] == 0.0                                   # entropy of the zero-temperature sampler
         assert abs(vals[1] - vals[3]) < 1e-6                    # F = E when S = 0
         assert not np.array_equal(flow.ravel(pf, dim), flow.ravel(p0, dim))
+    # finite temperature: the reference's Transformer density matrix trained together with the flow (hybrid SR, main.py:179-184)
+    M = 8
+    spm = sp[-M:]
+    van = cg.Transformer(M, 1, 8, 2, 16)
+    pv0 = van.init(2, spm[:n])
+    tsamp, tlogp = cg.make_autoregressive_sampler(van, spm, n, M)
+    pv, pf, rows = cg.train(flow, p0, spm, n, dim, L, rs=2.0, beta=1 / (4 * 0.15), batch=8, epochs=2, sampler=tsamp, log_prob=tlogp,
+                            params_van=pv0, sr=(1e-3, 1e-3), mc_therm=1, mc_steps=3, acc_steps=2, seed=1)
+    vals = [float(v) for v in rows[-1].split()]
+    assert all(np.isfinite(vals)) and vals[9] > 0.0            # entropy > 0 now
+    assert any(not np.array_equal(pv[m][l], pv0[m][l]) for m in pv for l in pv[m])
+    assert not np.array_equal(flow.ravel(pf, dim), flow.ravel(p0, dim))
 
 
 def test_checkpoint_interop(tmp_path):
@@ -293,3 +305,68 @@ def test_autoregressive_sampler_kats():
     assert abs(F.mean() - row[1]) < 5 * np.hypot(F.std() / np.sqrt(B), row[2])
     assert abs(Es[s].sum(-1).mean() - row[3]) < 5 * np.hypot(Es[s].sum(-1).std() / np.sqrt(B), row[4])
     assert abs(-lp.mean() - row[5]) < 5 * np.hypot(lp.std() / np.sqrt(B), row[6])
+
+
+def test_autoregressive_gradients_vs_torch_autograd():
+    """jax.grad(log_prob) of src/sampler.py:65 (classical score) and the weighted VJP: hand-written numpy reverse pass of
+    coulombgas_amd/autoregressive.py against autograd of the oracle's torch restatement."""
+    n, M, B = 5, 12, 6
+    sp = orbitals(2)[-M:]
+    van = cg.Transformer(M, 2, 16, 4, 32)
+    rng = np.random.default_rng(4)
+    params = van.init(rng, sp[:n])
+    for mod in params:                                       # larger weights than the init so that every path matters
+        for leaf in params[mod]:
+            params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M)
+    s = sampler(params, 2, B)
+    tp = {m: {l: R.T(v).requires_grad_(True) for l, v in params[m].items()} for m in params}
+    lps = [R.autoregressive_log_prob(tp, torch.as_tensor(s[b].astype(np.int64)), R.T(sp), 2, 4) for b in range(B)]
+    assert np.abs(log_prob(params, s) - np.array([float(v) for v in lps])).max() < 1e-12
+    leaves = [(m, l) for m in sorted(tp) for l in sorted(tp[m])]
+    g = log_prob.grad(params, s)
+    for b in range(B):
+        gr = torch.autograd.grad(lps[b], [tp[m][l] for m, l in leaves], retain_graph=True)
+        for (m, l), r in zip(leaves, gr):
+            assert np.abs(g[m][l][b] - r.numpy()).max() < 1e-12 * max(1.0, np.abs(r.numpy()).max()), (m, l)
+    w = rng.standard_normal(B)
+    v = log_prob.vjp(params, s, w)
+    for m, l in leaves:
+        assert np.abs(v[m][l] - np.tensordot(w, g[m][l], axes=1)).max() < 1e-12
+    sc = cg.make_classical_score(log_prob)(params, s)
+    from coulombgas_amd.sr import _ravel_batched
+    assert _ravel_batched(sc).shape == (B, sum(int(np.prod(params[m][l].shape)) for m, l in leaves))
+
+
+def test_freefermion_pretraining_and_exact_free_energy():
+    """src/freefermion/pretraining.py mirror: (i) the double-precision canonical recursion for F, E, S against brute-force
+    enumeration and against the published (sampled) free energies of the shipped pretrained models; (ii) natural-gradient
+    pre-training of a small density matrix lowers F towards the exact value (variational bound)."""
+    import itertools
+    from coulombgas_amd.freefermion import exact_free_energy, make_loss
+    sp = orbitals(2, 25)
+    n, Theta = 4, 0.15
+    L, beta = np.sqrt(np.pi * n), 1 / (4 * Theta)
+    sp10 = sp[-10:]
+    Es = (2 * np.pi / L) ** 2 * (sp10 ** 2).sum(-1)
+    Etot = np.array([Es[list(c)].sum() for c in itertools.combinations(range(10), n)])
+    w = np.exp(-beta * (Etot - Etot.min())); Z = w.sum()
+    F_bf = Etot.min() - np.log(Z) / beta; E_bf = (Etot * w).sum() / Z
+    F, E, S = exact_free_energy(Es, n, beta)
+    assert F == pytest.approx(F_bf, rel=1e-13) and E == pytest.approx(E_bf, rel=1e-12) and S == pytest.approx(beta * (E_bf - F_bf), rel=1e-10)
+    for nn, pub in ((13, 24.811018), (29, 54.701225)):            # data/freefermion/pretraining/*/*/data.txt:5000 (trained, sampled)
+        LL = np.sqrt(np.pi * nn)
+        Fx = exact_free_energy((2 * np.pi / LL) ** 2 * (sp ** 2).sum(-1), nn, beta)[0]
+        assert abs(Fx - pub) < 2e-4
+    van = cg.Transformer(10, 1, 8, 2, 16)
+    p0 = van.init(5, sp10[:n])
+    pv, rows = cg.pretrain(van, p0, n, 2, Theta, sp10, 11, sr=True, damping=1e-3, max_norm=1e-2, batch=1024, epoch=40)
+    v = np.array([[float(t) for t in r.split()] for r in rows])
+    assert v.shape == (40, 7) and np.isfinite(v).all()
+    assert v[-5:, 1].mean() < v[0, 1] - 5 * v[0, 2]               # F went down by many standard errors
+    assert v[-5:, 1].mean() > F - 5 * v[-5:, 2].mean()            # ... and respects the variational bound
+    _, log_prob = cg.make_autoregressive_sampler(van, sp10, n, 10)
+    loss = make_loss(log_prob, Es, beta)
+    s = np.array(list(itertools.combinations(range(10), n)))[:32]
+    val, aux = loss(pv, s)
+    assert np.isfinite(val) and set(aux) == {"E_mean", "E_std", "F_mean", "F_std", "S_mean", "S_std"}
