@@ -6,7 +6,18 @@ Gradients of log p w.r.t. the parameters (jax.grad(log_prob), src/sampler.py:65:
 and the VJP jax.jacrev(classical_lossfn) needs) come from a hand-written reverse pass of the same forward code
 (`log_prob.grad` / `log_prob.vjp` / `make_classical_score`).  Parameters keep Haiku's names and shapes, so shipped
 `params_van` (checkpoints, pretrained models) load unchanged."""
+import contextlib
 import numpy as np
+
+
+def _blas_limit():
+    """The model is tiny (16-wide): thousands of small batched matmuls.  On many-core hosts an unrestricted BLAS thread pool
+    turns each of them into a synchronisation storm (measured: minutes instead of milliseconds on a 256-thread box)."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=4, user_api="blas")
+    except Exception:
+        return contextlib.nullcontext()
 
 
 def _linear(p, x):
@@ -67,14 +78,15 @@ class Transformer:
         nm = "%s/layer%d_attn/" % (self.name, i)
         T = x.shape[-2]
         H, K = self.num_heads, self.key_size
-        split = lambda y: y.reshape(y.shape[:-1] + (H, K))
+        # heads to the front: (..., H, T, K); batched matmuls (numpy's einsum is ~5x slower on these shapes)
+        split = lambda y: np.swapaxes(y.reshape(y.shape[:-1] + (H, K)), -2, -3)
         q, k, v = (split(_linear(params[nm + part], x)) for part in ("query", "key", "value"))
-        logits = np.einsum("...thd,...Thd->...htT", q, k) / np.sqrt(K)
+        logits = (q @ np.swapaxes(k, -1, -2)) / np.sqrt(K)
         mask = np.tril(np.ones((T, T), dtype=bool))                                # CausalSelfAttention, :26-27
         logits = np.where(mask, logits, -1e30)
         logits = logits - logits.max(axis=-1, keepdims=True)
         w = np.exp(logits); w /= w.sum(axis=-1, keepdims=True)
-        attn = np.einsum("...htT,...Thd->...thd", w, v)
+        attn = np.swapaxes(w @ v, -2, -3)                                          # (..., T, H, K)
         return _linear(params[nm + "linear"], attn.reshape(attn.shape[:-2] + (H * K,)))
 
     def forward_cache(self, params, x):
@@ -87,12 +99,12 @@ class Transformer:
         mask = np.tril(np.ones((T, T), dtype=bool))
         for i in range(self.num_layers):
             an = "%s/layer%d_attn/" % (nm, i)
-            split = lambda y: y.reshape(y.shape[:-1] + (H, K))
+            split = lambda y: np.swapaxes(y.reshape(y.shape[:-1] + (H, K)), -2, -3)       # (B, H, T, K)
             q, k, v = (split(_linear(params[an + part], h)) for part in ("query", "key", "value"))
-            lg = np.where(mask, np.einsum("bthd,bThd->bhtT", q, k) / np.sqrt(K), -1e30)
+            lg = np.where(mask, (q @ np.swapaxes(k, -1, -2)) / np.sqrt(K), -1e30)
             lg = lg - lg.max(axis=-1, keepdims=True)
             A = np.exp(lg); A /= A.sum(axis=-1, keepdims=True)
-            o = np.einsum("bhtT,bThd->bthd", A, v).reshape(h.shape[:-1] + (H * K,))
+            o = np.swapaxes(A @ v, -2, -3).reshape(h.shape[:-1] + (H * K,))
             h1 = h + _linear(params[an + "linear"], o)
             m = np.tanh(_linear(params["%s/layer%d_mlp/linear" % (nm, i)], h1))
             h2 = h1 + _linear(params["%s/layer%d_mlp/linear_1" % (nm, i)], m)
@@ -109,7 +121,8 @@ class Transformer:
         per_sample, otherwise summed over the batch."""
         nm, H, K = self.name, self.num_heads, self.key_size
         B, T = dlogits.shape[0], dlogits.shape[1]
-        wsum = (lambda a, d: np.einsum("bti,bto->bio", a, d)) if per_sample else (lambda a, d: np.einsum("bti,bto->io", a, d))
+        wsum = ((lambda a, d: np.swapaxes(a, 1, 2) @ d) if per_sample else
+                (lambda a, d: a.reshape(-1, a.shape[-1]).T @ d.reshape(-1, d.shape[-1])))
         bsum = (lambda d: d.sum(axis=1)) if per_sample else (lambda d: d.sum(axis=(0, 1)))
         g = {nm: {"x1hat": dlogits[:, 0, :] if per_sample else dlogits[:, 0, :].sum(axis=0)}}
         dy = np.concatenate([dlogits[:, 1:, :], np.zeros((B, 1, self.output_size))], axis=1)
@@ -126,13 +139,14 @@ class Transformer:
             dh1 = dh + dpre @ p1["w"].T
             pl = params[an + "linear"]
             g[an + "linear"] = {"w": wsum(c["o"], dh1), "b": bsum(dh1)}
-            do = (dh1 @ pl["w"].T).reshape(B, T, H, K)
-            dA = np.einsum("bthd,bThd->bhtT", do, c["v"])
-            dv = np.einsum("bhtT,bthd->bThd", c["A"], do)
+            do = np.swapaxes((dh1 @ pl["w"].T).reshape(B, T, H, K), 1, 2)                  # (B, H, T, K)
+            dA = do @ np.swapaxes(c["v"], -1, -2)
+            dv = np.swapaxes(c["A"], -1, -2) @ do
             dS = c["A"] * (dA - (c["A"] * dA).sum(axis=-1, keepdims=True)) / np.sqrt(K)
-            dq = np.einsum("bhtT,bThd->bthd", dS, c["k"]).reshape(B, T, H * K)
-            dk = np.einsum("bhtT,bthd->bThd", dS, c["q"]).reshape(B, T, H * K)
-            dv = dv.reshape(B, T, H * K)
+            merge = lambda y: np.swapaxes(y, 1, 2).reshape(B, T, H * K)
+            dq = merge(dS @ c["k"])
+            dk = merge(np.swapaxes(dS, -1, -2) @ c["q"])
+            dv = merge(dv)
             dhin = dh1
             for part, d in (("query", dq), ("key", dk), ("value", dv)):
                 g[an + part] = {"w": wsum(c["hin"], d), "b": bsum(d)}
@@ -170,17 +184,24 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         return np.where(_mask(state_idx), logits, -1e50)
 
     def sampler(params, key, batch):
+        with _blas_limit():
+            return _sampler(params, key, batch)
+
+    def _sampler(params, key, batch):
         rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
         state_indices = np.zeros((batch, n), dtype=np.int32)
         for i in range(n):
-            logits = _logits(params, state_indices)[:, i, :]
+            # the conditional of electron i needs positions <= i only (causal attention): run the prefix, not all n
+            logits = network.apply(params, None, sp_indices[state_indices[:, :i + 1]])[:, i, :]
+            logits = np.where(_mask(state_indices)[:, i, :], logits, -1e50)
             g = -np.log(-np.log(rng.uniform(size=logits.shape)))                   # Gumbel-max = jax.random.categorical
             state_indices[:, i] = np.argmax(logits + g, axis=-1)
         return state_indices
 
     def log_prob(params, state_idx):
         state_idx = np.asarray(state_idx)
-        logits = _logits(params, state_idx)
+        with _blas_limit():
+            logits = _logits(params, state_idx)
         m = logits.max(axis=-1, keepdims=True)
         logp = logits - m - np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
         return np.take_along_axis(logp, state_idx[..., None], axis=-1)[..., 0].sum(axis=-1)
@@ -197,13 +218,15 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
 
     def grad(params, state_idx):
         """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients, every leaf with a leading batch axis."""
-        d, cache = _dlogits(params, state_idx)
-        return network.backward(params, cache, d, per_sample=True)
+        with _blas_limit():
+            d, cache = _dlogits(params, state_idx)
+            return network.backward(params, cache, d, per_sample=True)
 
     def vjp(params, state_idx, w):
         """sum_b w[b] * d log_prob_b / d params  (what jax.jacrev of a weighted sum of log-probabilities returns)."""
-        d, cache = _dlogits(params, state_idx)
-        return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)
+        with _blas_limit():
+            d, cache = _dlogits(params, state_idx)
+            return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)
 
     log_prob.grad, log_prob.vjp = grad, vjp
     if mask_fn:

@@ -1214,3 +1214,4 @@ int cg_scale_dev(cg_ctx* c, double* buf, size_t count, double s) {
 }  // extern "C"
 
 #include "cg_comm.inc"
+#include "cg_solve.inc"

@@ -268,6 +268,14 @@ class Engine:
             check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
         return F, sm[:, 0] + 1j * sm[:, 1]
 
+    def fisher_real(self, score):
+        """S^T S / B of a real (B, P) score matrix on the device (classical Fisher matrix, src/sr.py:36,74)."""
+        S = _f64(score)
+        B, P = S.shape
+        F = np.empty((P, P))
+        check(lib().cg_fisher_real(self._ctx, _p(S), B, P, _p(F)), self._ctx)
+        return F
+
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):
         assert self._mode == _lib.CG_PTR_DEVICE

@@ -41,8 +41,9 @@ def _ravel_batched(score):
     return np.concatenate([_ravel_batched(score[k]) for k in keys], axis=1)
 
 
-def _solve_and_clip(fisher, grads_raveled, damping, max_norm):
-    """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1)."""
+def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None):
+    """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  Host LAPACK (Cholesky),
+    once per optimisation step; `engine` is accepted for symmetry with the Fisher-matrix calls and unused."""
     from scipy.linalg import solve, LinAlgError
     fisher = fisher + damping * np.eye(fisher.shape[0])
     try:                                           # Fisher + damping I is symmetric positive definite: Cholesky
@@ -54,8 +55,9 @@ def _solve_and_clip(fisher, grads_raveled, damping, max_norm):
     return -scale * upd
 
 
-def fisher_sr(score_fn, damping, max_norm):
-    """src/sr.py:13-52: natural gradient for a purely classical model.  update(grads, state, (params, state_indices))."""
+def fisher_sr(score_fn, damping, max_norm, engine=None):
+    """src/sr.py:13-52: natural gradient for a purely classical model.  update(grads, state, (params, state_indices)).
+    engine (optional): a coulombgas_amd Engine whose GPU forms the Fisher matrix."""
     def init_fn(params):
         return EmptyState()
 
@@ -63,8 +65,8 @@ def fisher_sr(score_fn, damping, max_norm):
         params, state_indices = params
         g, unravel = ravel_pytree(grads)
         score = _ravel_batched(score_fn(params, state_indices))
-        fisher = score.T.dot(score) / score.shape[0]
-        return unravel(_solve_and_clip(fisher, g, damping, max_norm)), state
+        fisher = engine.fisher_real(score) if engine is not None and hasattr(engine, "fisher_real") else score.T.dot(score) / score.shape[0]
+        return unravel(_solve_and_clip(fisher, g, damping, max_norm, engine)), state
 
     return GradientTransformation(init_fn, update_fn)
 
@@ -75,14 +77,17 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
     averaged over the ranks (the reference's pmean, :70-76).  `quantum_score_fn` is make_quantum_score(logpsi): its wave
     function's engine computes Re(S^H S)/B and mean(S) on the GPU without moving the (B, P) score matrix to the host."""
     wf = quantum_score_fn.wf
+    last_engine = [None]
 
     def fishers_fn(params_van, params_flow, state_indices, x):
         cm = comm or get_comm()
+        eng = wf.engine(x, params_flow)
+        last_engine[0] = eng
         classical_fisher = None
         if classical_score_fn is not None:
             cs = _ravel_batched(classical_score_fn(params_van, state_indices))
-            classical_fisher = cm.pmean(cs.T.dot(cs) / cs.shape[0])
-        eng = wf.engine(x, params_flow)
+            cf = eng.fisher_real(cs) if hasattr(eng, "fisher_real") else cs.T.dot(cs) / cs.shape[0]
+            classical_fisher = cm.pmean(cf)
         qf, qmean = eng.quantum_fisher(x, state_indices)
         packed = cm.pmean(np.concatenate([qf.reshape(-1), qmean.real, qmean.imag]))      # one all-reduce
         P = qmean.shape[0]
@@ -98,9 +103,9 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
         update_van = None
         if grad_params_van is not None and classical_fisher is not None:
             gv, unravel_van = ravel_pytree(grad_params_van)
-            update_van = unravel_van(_solve_and_clip(classical_fisher, gv, damping, max_norm))
+            update_van = unravel_van(_solve_and_clip(classical_fisher, gv, damping, max_norm, last_engine[0]))
         gf, unravel_flow = ravel_pytree(grad_params_flow)
-        update_flow = unravel_flow(_solve_and_clip(quantum_fisher, gf, damping, max_norm))
+        update_flow = unravel_flow(_solve_and_clip(quantum_fisher, gf, damping, max_norm, last_engine[0]))
         return (update_van, update_flow), state
 
     return fishers_fn, GradientTransformation(init_fn, update_fn)

@@ -141,6 +141,10 @@ int cg_scores_compute(cg_ctx* ctx, const double* x, const int32_t* state_idx, in
 int cg_scores_vjp(cg_ctx* ctx, const double* w_re, const double* w_im, double* g_theta);
 int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
 
+/* Classical Fisher matrix of the SR optimizer (src/sr.py:36, 74) on the device: F (P,P) = S^T S / B for a real (B,P) score
+ * matrix, f64 MFMA.  (The damped Cholesky solve of src/sr.py:38-45 is a host LAPACK call in coulombgas_amd/sr.py.) */
+int cg_fisher_real(cg_ctx* ctx, const double* S, int B, int P, double* F);
+
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
 
 /* RCCL communicator over the ranks of one node; replaces jax.lax.pmean(axis_name="p")

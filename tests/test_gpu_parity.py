@@ -457,6 +457,10 @@ def test_quantum_fisher_and_sr_update(case, depth):
     Fr = (qs.conj().T @ qs).real / B
     assert np.abs(F - Fr).max() < 1e-10 * np.abs(Fr).max() and np.abs(F - F.T).max() == 0.0
     assert np.abs(sm - qs.mean(axis=0)).max() < 1e-10 * np.abs(qs).max()
+    # classical Fisher matrix on the device: real SYRK
+    cs = rng.standard_normal((37, 53))
+    Fc = eng.fisher_real(cs)
+    assert np.abs(Fc - cs.T @ cs / 37).max() < 1e-13 * np.abs(Fc).max() and np.abs(Fc - Fc.T).max() == 0.0
     fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(logpsi), 1e-3, 1e-3)
     params_flow = flow.unravel(theta, dim)
     cf, qf, qm = fishers_fn(None, params_flow, sidx, x)
