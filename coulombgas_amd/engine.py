@@ -276,6 +276,13 @@ class Engine:
         check(lib().cg_fisher_real(self._ctx, _p(S), B, P, _p(F)), self._ctx)
         return F
 
+    def cholesky(self, A):
+        """Lower Cholesky factor of a symmetric positive definite matrix on the device (blocked, f64 MFMA); returns L
+        with zeros above the diagonal."""
+        L = np.array(A, dtype=np.float64, order="C")
+        check(lib().cg_cholesky(self._ctx, _p(L), L.shape[0]), self._ctx)
+        return np.tril(L)
+
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):
         assert self._mode == _lib.CG_PTR_DEVICE

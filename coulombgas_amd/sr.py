@@ -42,14 +42,23 @@ def _ravel_batched(score):
 
 
 def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None):
-    """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  Host LAPACK (Cholesky),
-    once per optimisation step; `engine` is accepted for symmetry with the Fisher-matrix calls and unused."""
-    from scipy.linalg import solve, LinAlgError
+    """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  With an engine the
+    O(P^3) Cholesky factorisation runs on the GPU (cg_cholesky) and only the two O(P^2) triangular solves on the host;
+    host LAPACK otherwise (and if round-off made the matrix indefinite)."""
+    from scipy.linalg import solve, solve_triangular, LinAlgError
     fisher = fisher + damping * np.eye(fisher.shape[0])
-    try:                                           # Fisher + damping I is symmetric positive definite: Cholesky
-        upd = solve(fisher, grads_raveled, assume_a="pos")
-    except LinAlgError:                            # (round-off made it indefinite: fall back to the symmetric solver)
-        upd = solve(fisher, grads_raveled, assume_a="sym")
+    upd = None
+    if engine is not None and hasattr(engine, "cholesky") and fisher.shape[0] >= 512:
+        try:
+            L = engine.cholesky(fisher)
+            upd = solve_triangular(L, solve_triangular(L, grads_raveled, lower=True), lower=True, trans="T")
+        except Exception:
+            upd = None
+    if upd is None:
+        try:                                       # Fisher + damping I is symmetric positive definite: Cholesky
+            upd = solve(fisher, grads_raveled, assume_a="pos")
+        except LinAlgError:                        # (round-off made it indefinite: fall back to the symmetric solver)
+            upd = solve(fisher, grads_raveled, assume_a="sym")
     gnorm = float(np.sum(grads_raveled * upd))
     scale = min(np.sqrt(max_norm / gnorm), 1.0) if gnorm > 0 else 1.0
     return -scale * upd

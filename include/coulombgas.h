@@ -142,8 +142,11 @@ int cg_scores_vjp(cg_ctx* ctx, const double* w_re, const double* w_im, double* g
 int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
 
 /* Classical Fisher matrix of the SR optimizer (src/sr.py:36, 74) on the device: F (P,P) = S^T S / B for a real (B,P) score
- * matrix, f64 MFMA.  (The damped Cholesky solve of src/sr.py:38-45 is a host LAPACK call in coulombgas_amd/sr.py.) */
+ * matrix, f64 MFMA. */
 int cg_fisher_real(cg_ctx* ctx, const double* S, int B, int P, double* F);
+/* In-place blocked Cholesky (f64 MFMA trailing updates) for the damped SR solve (src/sr.py:38-45, 102-117): on return the
+ * lower triangle of A (P,P) holds L, A = L L^T; the strict upper triangle is untouched.  CG_ERR_STATE if not positive definite. */
+int cg_cholesky(cg_ctx* ctx, double* A, int P);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
 

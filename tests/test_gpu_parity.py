@@ -457,10 +457,17 @@ def test_quantum_fisher_and_sr_update(case, depth):
     Fr = (qs.conj().T @ qs).real / B
     assert np.abs(F - Fr).max() < 1e-10 * np.abs(Fr).max() and np.abs(F - F.T).max() == 0.0
     assert np.abs(sm - qs.mean(axis=0)).max() < 1e-10 * np.abs(qs).max()
-    # classical Fisher matrix on the device: real SYRK
+    # classical Fisher matrix on the device: real SYRK; blocked Cholesky of the damped matrices
     cs = rng.standard_normal((37, 53))
     Fc = eng.fisher_real(cs)
     assert np.abs(Fc - cs.T @ cs / 37).max() < 1e-13 * np.abs(Fc).max() and np.abs(Fc - Fc.T).max() == 0.0
+    for M in (Fc + 1e-3 * np.eye(53), Fr + 1e-3 * np.eye(theta.size)):
+        Lg = eng.cholesky(M)
+        Lr = np.linalg.cholesky(M)
+        assert np.abs(Lg - Lr).max() < 1e-9 * np.abs(Lr).max() and np.abs(Lg @ Lg.T - M).max() < 1e-12 * np.abs(M).max()
+    from coulombgas_amd._lib import CoulombGasError
+    with pytest.raises(CoulombGasError):
+        eng.cholesky(np.diag([1.0, -1.0, 2.0]))
     fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(logpsi), 1e-3, 1e-3)
     params_flow = flow.unravel(theta, dim)
     cf, qf, qm = fishers_fn(None, params_flow, sidx, x)
