@@ -79,7 +79,7 @@ struct CgDerivs {
         l.oj = l.jets_in_lds ? al : l.o;
         return l;
     }
-    static size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
+    static CG_HD size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }
 
@@ -88,21 +88,31 @@ struct CgDerivs {
     // ------------------------------------------------------------------------------------------------------
     static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                              double* ws, const Ws& w, const CgFastLds& o, bool need_T) {
+                              double* ws, const Ws& w, const CgFastLds& o, bool need_T,
+                              double* fast = nullptr, size_t fast_cap = 0, bool da_fast = false) {
+        // fast: LDS scratch that is dead during the set-up (the Jet2 arena of the directional passes).  The two
+        // Gauss-Jordan inversions (one barrier-separated step per column) and, when the caller does not need the
+        // primal arena afterwards (da_fast), the primal + Jacobian evaluation run there instead of in the HBM workspace.
         const int N = n * D;
-        double* da = ws + w.da; double* x = ws + w.x;
+        const size_t inv_need = 2 * (size_t)N * N + 4 * (size_t)n * n + N + 42;
+        const bool inv_lds = fast && fast_cap >= (da_fast ? (size_t)o.total : 0) + inv_need;
+        da_fast = da_fast && inv_lds;
+        double* da = da_fast ? fast : ws + w.da; double* x = ws + w.x;
+        double* sc = inv_lds ? fast + (da_fast ? (size_t)o.total : 0) : nullptr;
         for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
         b.sync();
         F::primal(b, th, (const double*)x, n, L, da, o);
         F::jacobian(b, th, n, L, da, o);
-        double* Jc = ws + w.Jc; double* Jinv = ws + w.Jinv;
+        double* Jc = inv_lds ? sc : ws + w.Jc; double* Jinv = inv_lds ? sc + (size_t)N * N : ws + w.Jinv;
         for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
         b.sync();
-        int* perm = (int*)(ws + w.perm);
+        int* perm = inv_lds ? (int*)(sc + 2 * (size_t)N * N + 4 * (size_t)n * n) : (int*)(ws + w.perm);
         (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-        double* Dc = ws + w.Dc; double* Dinv = ws + w.Dinv;
+        double* Dc = inv_lds ? sc + 2 * (size_t)N * N : ws + w.Dc;
+        double* Dinv = inv_lds ? Dc + 2 * (size_t)n * n : ws + w.Dinv;
         F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
         for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+        if (inv_lds) for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
         b.sync();
         double la, ar;
         cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
@@ -193,7 +203,8 @@ struct CgDerivs {
         const Ws& w = lay.w;
         const CgFastLds& o = lay.o;
         CG_STAMP_START(20)
-        setup(b, th, xg, spk, sidx, n, L, ws, w, o, true);
+        setup(b, th, xg, spk, sidx, n, L, ws, w, o, true, lay.jets_in_lds ? lds + lds_doubles(n, b.nthr) : nullptr,
+              jet_lds_doubles(lay), true);
         CG_STAMP_END(20)
         const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
         const double* gz = ws + w.gz; double* M = ws + w.M;
