@@ -70,16 +70,24 @@ struct CgDerivs {
     // oj: layout of the Jet2 arena of the directional passes.  When 3 * oj.total doubles fit the LDS (aliased sampler
     // layout: the passes need primal + Jacobian lifetimes only) the arena lives there -- the passes are latency-bound on
     // their ~25 barrier-separated phases and an L2 round trip per access made them ~10x slower than their arithmetic.
-    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; };
+    // vjp_fast / vjp_da: LDS scratch of the theta-VJP kernel (doubles; 0 = none) and whether the primal arena lives there.
+    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; int vjp_fast; int vjp_da; };
     static constexpr size_t JET_LDS_MAX_BYTES = 150 * 1024;
+    static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
+    static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
     static Layout layout(int n, int nthr = 256) {
         Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
         const CgFastLds al = cg_fast_layout(n, D, HS, HT, true, false);
         l.jets_in_lds = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total) <= JET_LDS_MAX_BYTES ? 1 : 0;
         l.oj = l.jets_in_lds ? al : l.o;
+        const size_t base = CG_TAB_DOUBLES + lds_doubles(n, nthr), inv = inv_scratch_doubles(n), NN = (size_t)n * D * n * D;
+        l.vjp_fast = 0; l.vjp_da = 0;
+        if (sizeof(double) * (base + l.o.total + inv - NN) <= VJP_LDS_MAX_BYTES) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
+        else if (sizeof(double) * (base + inv) <= VJP_LDS_MAX_BYTES) l.vjp_fast = (int)inv;
         return l;
     }
     static CG_HD size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
+    static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)l.vjp_fast; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }
 
@@ -94,22 +102,27 @@ struct CgDerivs {
         // Gauss-Jordan inversions (one barrier-separated step per column) and, when the caller does not need the
         // primal arena afterwards (da_fast), the primal + Jacobian evaluation run there instead of in the HBM workspace.
         const int N = n * D;
-        const size_t inv_need = 2 * (size_t)N * N + 4 * (size_t)n * n + N + 42;
-        const bool inv_lds = fast && fast_cap >= (da_fast ? (size_t)o.total : 0) + inv_need;
-        da_fast = da_fast && inv_lds;
+        const size_t NN = (size_t)N * N, nn2 = 2 * (size_t)n * n;
+        da_fast = da_fast && fast && fast_cap >= (size_t)o.total + inv_scratch_doubles(n) - NN;
+        const bool inv_lds = da_fast || (fast && fast_cap >= inv_scratch_doubles(n));
         double* da = da_fast ? fast : ws + w.da; double* x = ws + w.x;
         double* sc = inv_lds ? fast + (da_fast ? (size_t)o.total : 0) : nullptr;
         for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
         b.sync();
         F::primal(b, th, (const double*)x, n, L, da, o);
         F::jacobian(b, th, n, L, da, o);
-        double* Jc = inv_lds ? sc : ws + w.Jc; double* Jinv = inv_lds ? sc + (size_t)N * N : ws + w.Jinv;
-        for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
-        b.sync();
-        int* perm = inv_lds ? (int*)(sc + 2 * (size_t)N * N + 4 * (size_t)n * n) : (int*)(ws + w.perm);
+        // with the arena in LDS its J slot (dead after the set-up) is inverted in place
+        double* Jc = da_fast ? da + o.J : (inv_lds ? sc : ws + w.Jc);
+        if (inv_lds && !da_fast) sc += NN;
+        double* Jinv = inv_lds ? sc : ws + w.Jinv;
+        double* Dc = inv_lds ? sc + NN : ws + w.Dc;
+        double* Dinv = inv_lds ? sc + NN + nn2 : ws + w.Dinv;
+        int* perm = inv_lds ? (int*)(sc + NN + 2 * nn2) : (int*)(ws + w.perm);
+        if (!da_fast) {
+            for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+            b.sync();
+        }
         (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-        double* Dc = inv_lds ? sc + 2 * (size_t)N * N : ws + w.Dc;
-        double* Dinv = inv_lds ? Dc + 2 * (size_t)n * n : ws + w.Dinv;
         F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
         for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
         if (inv_lds) for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
@@ -298,10 +311,9 @@ struct CgDerivs {
 
     // One reverse sweep for cotangents (zbar, Jbar); adds the parameter gradient into gw[NP] (gw zeroed by caller).
     static CG_DEVI void reverse(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                const CgFastLds& o, const Adj& A, double* gw) {
+                                const CgFastLds& o, const Adj& A, double* gw, const double* da) {
         const int N = n * D;
         double* ad = ws + w.adj;
-        const double* da = ws + w.da;
         const double *sh = da + o.sh, *ch = da + o.ch, *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
                      *gbar = da + o.gbar, *sg2 = da + o.sg2, *s2 = da + o.s2, *U = da + o.U, *V = da + o.V,
                      *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
@@ -592,7 +604,9 @@ struct CgDerivs {
         const int N = n * D;
         const Ws& w = lay.w;
         const CgFastLds& o = lay.o;
-        setup(b, th, xg, spk, sidx, n, L, ws, w, o, false);
+        double* fast = lay.vjp_fast ? lds + lds_doubles(n, b.nthr) : nullptr;
+        setup(b, th, xg, spk, sidx, n, L, ws, w, o, false, fast, (size_t)lay.vjp_fast, lay.vjp_da != 0);
+        const double* da = lay.vjp_da ? fast : ws + w.da;       // primal arena the reverse sweeps read
         const double* Jinv = ws + w.Jinv; const double* gz = ws + w.gz;
         double* zbar = ws + w.zbar; double* Jbar = ws + w.Jbar; double* gw = ws + w.gw;
         const int npass = score ? 2 : 1;
@@ -603,7 +617,7 @@ struct CgDerivs {
             for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
             for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
             b.sync();
-            reverse(b, th, n, L, ws, w, o, lay.a, gw);
+            reverse(b, th, n, L, ws, w, o, lay.a, gw, da);
             if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
             else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];
             b.sync();

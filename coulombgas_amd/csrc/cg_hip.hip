@@ -1094,12 +1094,13 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
 #define CG_X(D, HS, HT)                                                                                               \
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \
-        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt));                                 \
+        const auto dl = CgDerivs<D, HS, HT>::layout(n, nt);                                                          \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::vjp_lds_doubles(dl)); \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
         if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
         hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
                            (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
-                           (double*)asc.dev, (double*)c->ws, wsw, CgDerivs<D, HS, HT>::layout(n));                   \
+                           (double*)asc.dev, (double*)c->ws, wsw, dl);                                               \
         launched = true;                                                                                             \
     }
     CG_FAST_CONFIGS(CG_X)

@@ -67,13 +67,14 @@ template <int D, int HS, int HT>
 static void emu_vjp_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
                       const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
     using G = CgDerivs<D, HS, HT>;
-    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + 8), spk((size_t)M * D);
+    const auto lay = G::layout(n, 1);              // same LDS scratch decisions as the GPU launch
+    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + G::vjp_lds_doubles(lay) + 8), spk((size_t)M * D);
     for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
     CgBlk b{0, 1};
     if (g) for (int e = 0; e < G::NP; ++e) g[e] = 0.0;
     for (int w = 0; w < B; ++w)
         G::param_vjp(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, w_re ? w_re[w] : 1.0,
-                     w_im ? w_im[w] : 0.0, g, score ? score + (size_t)w * G::NP * 2 : nullptr, ws.data(), lds.data(), G::layout(n));
+                     w_im ? w_im[w] : 0.0, g, score ? score + (size_t)w * G::NP * 2 : nullptr, ws.data(), lds.data(), lay);
 }
 extern "C" int emu_param_vjp(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
                              const int* sidx, const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
