@@ -311,14 +311,26 @@ struct CgDerivs {
 
     // One reverse sweep for cotangents (zbar, Jbar); adds the parameter gradient into gw[NP] (gw zeroed by caller).
     static CG_DEVI void reverse(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                const CgFastLds& o, const Adj& A, double* gw, const double* da) {
+                                const CgFastLds& o, const Adj& A, double* gw, const double* da,
+                                double* jslot = nullptr, double* hot = nullptr, size_t hot_cap = 0) {
+        // jslot / hot: LDS that is dead during the sweep (the arena's J slot, the set-up's inversion scratch); the adjoint
+        // arrays of the pair loops (Jhat; Gbar, Bbar, Vbar, U'bar while they fit) live there instead of in the HBM workspace.
         const int N = n * D;
         double* ad = ws + w.adj;
+        size_t hot_left = hot ? hot_cap : 0;
+        auto pick = [&](double* dflt, size_t cnt) {
+            cnt = (cnt + 1) & ~(size_t)1;
+            if (hot_left < cnt) return dflt;
+            double* r = hot; hot += cnt; hot_left -= cnt; return r;
+        };
         const double *sh = da + o.sh, *ch = da + o.ch, *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
                      *gbar = da + o.gbar, *sg2 = da + o.sg2, *s2 = da + o.s2, *U = da + o.U, *V = da + o.V,
                      *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
         const double* zbar = ws + w.zbar; const double* Jbar = ws + w.Jbar;
-        double *Jhat = ad + A.Jhat, *Upb = ad + A.Upb, *Vb = ad + A.Vb, *Bb = ad + A.Bb, *Gb = ad + A.Gb, *sg1b = ad + A.sg1b,
+        double* Jhat = jslot ? jslot : ad + A.Jhat;
+        double* Gb = pick(ad + A.Gb, (size_t)n * HS * D); double* Bb = pick(ad + A.Bb, (size_t)N * HS);
+        double* Vb = pick(ad + A.Vb, (size_t)N * HT); double* Upb = pick(ad + A.Upb, (size_t)N * P);
+        double *sg1b = ad + A.sg1b,
                *sg2b = ad + A.sg2b, *Ub = ad + A.Ub, *Rb = ad + A.Rb, *s1b = ad + A.s1b, *s2b = ad + A.s2b, *u2b = ad + A.u2b,
                *u1b = ad + A.u1b, *m1b = ad + A.m1b, *gbb = ad + A.gbb, *pW0 = ad + A.pW0, *pWt = ad + A.pWt, *su2 = ad + A.su2;
         const double rn = 1.0 / (double)n;
@@ -617,7 +629,8 @@ struct CgDerivs {
             for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
             for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
             b.sync();
-            reverse(b, th, n, L, ws, w, o, lay.a, gw, da);
+            reverse(b, th, n, L, ws, w, o, lay.a, gw, da, lay.vjp_da ? fast + o.J : nullptr,
+                    lay.vjp_da ? fast + o.total : nullptr, lay.vjp_da ? (size_t)lay.vjp_fast - o.total : 0);
             if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
             else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];
             b.sync();
