@@ -71,7 +71,8 @@ struct CgDerivs {
     // layout: the passes need primal + Jacobian lifetimes only) the arena lives there -- the passes are latency-bound on
     // their ~25 barrier-separated phases and an L2 round trip per access made them ~10x slower than their arithmetic.
     // vjp_fast / vjp_da: LDS scratch of the theta-VJP kernel (doubles; 0 = none) and whether the primal arena lives there.
-    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; int vjp_fast; int vjp_da; };
+    // theta_lds: the grad/Laplacian kernel copies theta behind its jet arena (when that costs no workgroup per CU).
+    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; int vjp_fast; int vjp_da; int theta_lds; };
     static constexpr size_t JET_LDS_MAX_BYTES = 150 * 1024;
     static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
     static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
@@ -80,6 +81,13 @@ struct CgDerivs {
         const CgFastLds al = cg_fast_layout(n, D, HS, HT, true, false);
         l.jets_in_lds = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total) <= JET_LDS_MAX_BYTES ? 1 : 0;
         l.oj = l.jets_in_lds ? al : l.o;
+        l.theta_lds = 0;
+        if (l.jets_in_lds) {
+            const size_t now = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total), with = now + sizeof(double) * NP;
+            const size_t lds_cu = 160 * 1024;
+            auto wgs = [&](size_t bytes) { const size_t k = lds_cu / bytes; return k > 2 ? (size_t)2 : k; };
+            l.theta_lds = with <= lds_cu && wgs(with) == wgs(now) ? 1 : 0;
+        }
         const size_t base = CG_TAB_DOUBLES + lds_doubles(n, nthr), inv = inv_scratch_doubles(n), NN = (size_t)n * D * n * D;
         l.vjp_fast = 0; l.vjp_da = 0;
         if (sizeof(double) * (base + l.o.total + inv - NN) <= VJP_LDS_MAX_BYTES) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
@@ -87,6 +95,7 @@ struct CgDerivs {
         return l;
     }
     static CG_HD size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
+    static CG_HD size_t theta_lds_doubles(const Layout& l) { return l.theta_lds ? (size_t)NP : 0; }
     static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)l.vjp_fast; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }

@@ -200,8 +200,15 @@ __global__ void __launch_bounds__(256, (JLDS ? (CG_DERIV_WAVES_OF(D) < 2 ? CG_DE
     __syncthreads();
     CG_STAMP_INIT
     const int n = m.n, N = n * D;
+    const double* th = theta;
+    if (JLDS && lay.theta_lds) {         // per-lane weight reads of the jet passes from LDS instead of the vector L1
+        double* th_l = lds + CgDerivs<D, HS, HT>::lds_doubles(n, b.nthr) + CgDerivs<D, HS, HT>::jet_lds_doubles(lay);
+        for (int e = b.tid; e < CgFast<D, HS, HT>::NPARAM; e += b.nthr) th_l[e] = theta[e];
+        __syncthreads();
+        th = th_l;
+    }
     for (int w = blockIdx.x; w < B; w += gridDim.x) {
-        CgDerivs<D, HS, HT>::grad_laplacian(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
+        CgDerivs<D, HS, HT>::grad_laplacian(b, th, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
                                             v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
                                             ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
         b.sync();
@@ -1025,7 +1032,7 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
         const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                      \
         const auto dl = CgDerivs<D, HS, HT>::layout(n, nt);                                                         \
-        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::jet_lds_doubles(dl)); \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::jet_lds_doubles(dl) + CgDerivs<D, HS, HT>::theta_lds_doubles(dl)); \
         if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                            \
         if (dl.jets_in_lds) {                                                                                       \
             if ((rc = set_lds(c, k_grad_lap<D, HS, HT, true>, lds))) return rc;                                     \
