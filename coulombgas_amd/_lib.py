@@ -65,6 +65,7 @@ PROTOTYPES = {
     "cg_scores_fisher": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_fisher_real": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cg_cholesky": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cg_spd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_comm_unique_id": (C.c_int, [C.c_void_p]),
     "cg_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cg_comm_destroy": (None, [C.c_void_p]),

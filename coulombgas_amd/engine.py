@@ -283,6 +283,21 @@ class Engine:
         check(lib().cg_cholesky(self._ctx, _p(L), L.shape[0]), self._ctx)
         return np.tril(L)
 
+    def spd_solve(self, A, b, damping=0.0, center=None):
+        """(A - Re(conj(m) m^T) + damping I)^-1 b, entirely on the device (optional centring with the complex vector
+        m = center, shift, blocked Cholesky, both triangular solves): the damped solve of src/sr.py:38-41 / 88, 102-112.
+        Raises if the matrix is not positive definite."""
+        A = _f64(A); b = _f64(b).reshape(-1)
+        assert A.shape == (b.size, b.size)
+        x = np.empty(b.size)
+        cre = cim = None
+        if center is not None:
+            center = np.asarray(center).reshape(-1)
+            assert center.size == b.size
+            cre, cim = _f64(center.real), _f64(center.imag)
+        check(lib().cg_spd_solve(self._ctx, _p(A), b.size, float(damping), _p(cre), _p(cim), _p(b), _p(x)), self._ctx)
+        return x
+
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):
         assert self._mode == _lib.CG_PTR_DEVICE

@@ -41,20 +41,24 @@ def _ravel_batched(score):
     return np.concatenate([_ravel_batched(score[k]) for k in keys], axis=1)
 
 
-def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None):
+def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, center=None):
     """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  With an engine the
-    O(P^3) Cholesky factorisation runs on the GPU (cg_cholesky) and only the two O(P^2) triangular solves on the host;
-    host LAPACK otherwise (and if round-off made the matrix indefinite)."""
-    from scipy.linalg import solve, solve_triangular, LinAlgError
-    fisher = fisher + damping * np.eye(fisher.shape[0])
+    damped solve runs on the GPU (cg_spd_solve: shift, blocked Cholesky, both triangular solves); host LAPACK otherwise
+    (small systems, and if round-off made the matrix indefinite).  center: complex score mean m; the matrix solved is
+    F - Re(conj(m) m^T) (src/sr.py:88)."""
+    from scipy.linalg import solve, LinAlgError
     upd = None
-    if engine is not None and hasattr(engine, "cholesky") and fisher.shape[0] >= 512:
+    if engine is not None and hasattr(engine, "spd_solve") and fisher.shape[0] >= 512:
         try:
-            L = engine.cholesky(fisher)
-            upd = solve_triangular(L, solve_triangular(L, grads_raveled, lower=True), lower=True, trans="T")
+            upd = engine.spd_solve(fisher, grads_raveled, damping, center)
+            if not np.isfinite(upd).all():
+                upd = None
         except Exception:
             upd = None
     if upd is None:
+        if center is not None:                     # src/sr.py:88
+            fisher = fisher - np.outer(center.real, center.real) - np.outer(center.imag, center.imag)
+        fisher = fisher + damping * np.eye(fisher.shape[0])
         try:                                       # Fisher + damping I is symmetric positive definite: Cholesky
             upd = solve(fisher, grads_raveled, assume_a="pos")
         except LinAlgError:                        # (round-off made it indefinite: fall back to the symmetric solver)
@@ -108,13 +112,14 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
     def update_fn(grads, state, params):
         grad_params_van, grad_params_flow = grads
         classical_fisher, quantum_fisher, quantum_score_mean = params
-        quantum_fisher = quantum_fisher - (quantum_score_mean.conj()[:, None] * quantum_score_mean).real   # :88
         update_van = None
         if grad_params_van is not None and classical_fisher is not None:
             gv, unravel_van = ravel_pytree(grad_params_van)
             update_van = unravel_van(_solve_and_clip(classical_fisher, gv, damping, max_norm, last_engine[0]))
         gf, unravel_flow = ravel_pytree(grad_params_flow)
-        update_flow = unravel_flow(_solve_and_clip(quantum_fisher, gf, damping, max_norm, last_engine[0]))
+        # the centring of :88, F - Re(conj(m) m^T), is applied inside the solve (on the device when there is one)
+        update_flow = unravel_flow(_solve_and_clip(quantum_fisher, gf, damping, max_norm, last_engine[0],
+                                                   center=np.asarray(quantum_score_mean)))
         return (update_van, update_flow), state
 
     return fishers_fn, GradientTransformation(init_fn, update_fn)

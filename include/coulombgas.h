@@ -147,6 +147,12 @@ int cg_fisher_real(cg_ctx* ctx, const double* S, int B, int P, double* F);
 /* In-place blocked Cholesky (f64 MFMA trailing updates) for the damped SR solve (src/sr.py:38-45, 102-117): on return the
  * lower triangle of A (P,P) holds L, A = L L^T; the strict upper triangle is untouched.  CG_ERR_STATE if not positive definite. */
 int cg_cholesky(cg_ctx* ctx, double* A, int P);
+/* The whole damped solve of src/sr.py:38-41 / 88, 102-112 on the device: x = (A - Re(conj(m) m^T) + damping I)^-1 b for a
+ * symmetric A (P,P) whose shifted form is positive definite: optional centring with m = center_re + i center_im (both NULL:
+ * none), diagonal shift, blocked Cholesky, forward and transposed substitution in 64-row blocks.  Host-pointer mode leaves
+ * the caller's A intact; in device-pointer mode A is overwritten by its factor.  b and x may be the same array. */
+int cg_spd_solve(cg_ctx* ctx, double* A, int P, double damping, const double* center_re, const double* center_im,
+                 const double* b, double* x);
 
 /* ---- multi-GPU (one process per GPU) ------------------------------------------------------ */
 

@@ -461,13 +461,23 @@ def test_quantum_fisher_and_sr_update(case, depth):
     cs = rng.standard_normal((37, 53))
     Fc = eng.fisher_real(cs)
     assert np.abs(Fc - cs.T @ cs / 37).max() < 1e-13 * np.abs(Fc).max() and np.abs(Fc - Fc.T).max() == 0.0
-    for M in (Fc + 1e-3 * np.eye(53), Fr + 1e-3 * np.eye(theta.size)):
+    for M, mc in ((Fc + 1e-3 * np.eye(53), cs.mean(axis=0) + 0j), (Fr + 1e-3 * np.eye(theta.size), qs.mean(axis=0))):
         Lg = eng.cholesky(M)
         Lr = np.linalg.cholesky(M)
         assert np.abs(Lg - Lr).max() < 1e-9 * np.abs(Lr).max() and np.abs(Lg @ Lg.T - M).max() < 1e-12 * np.abs(M).max()
+        # the whole damped solve on the device (shift, factor, both substitutions) against LAPACK; the input stays intact
+        rhs = rng.standard_normal(M.shape[0]); M0 = M.copy()
+        xg = eng.spd_solve(M, rhs, 2e-3)
+        xr = np.linalg.solve(M + 2e-3 * np.eye(M.shape[0]), rhs)
+        assert np.abs(xg - xr).max() < 1e-9 * np.abs(xr).max() and np.array_equal(M, M0)
+        xg = eng.spd_solve(M, rhs, 2e-3, center=mc)            # centred: the covariance of the scores (src/sr.py:88)
+        xr = np.linalg.solve(M - (mc.conj()[:, None] * mc).real + 2e-3 * np.eye(M.shape[0]), rhs)
+        assert np.abs(xg - xr).max() < 1e-8 * np.abs(xr).max() and np.array_equal(M, M0)
     from coulombgas_amd._lib import CoulombGasError
     with pytest.raises(CoulombGasError):
         eng.cholesky(np.diag([1.0, -1.0, 2.0]))
+    with pytest.raises(CoulombGasError):
+        eng.spd_solve(np.diag([1.0, -1.0, 2.0]), np.ones(3))
     fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(logpsi), 1e-3, 1e-3)
     params_flow = flow.unravel(theta, dim)
     cf, qf, qm = fishers_fn(None, params_flow, sidx, x)
