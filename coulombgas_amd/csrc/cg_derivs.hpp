@@ -206,14 +206,26 @@ struct CgDerivs {
         const int off[4] = {o.sh, o.ch, o.sg1, o.sg2};
         for (int e = b.tid; e < N; e += b.nthr) zsave[e] = ja[o.z + e];
         // carry sh, ch, sg1, sg2 over in chunks of nthr elements (read all, barrier, write all: the arenas overlap)
-        for (int q = 0; q < 4; ++q)
-            for (int e0 = 0; e0 < cnt[q]; e0 += b.nthr) {
-                const int e = e0 + b.tid;
-                Jet2 v; if (e < cnt[q]) v = ja[off[q] + e];
-                b.sync();
-                if (e < cnt[q]) da2[off[q] + e] = Dual(v.v, v.d);
-                b.sync();
-            }
+        const int cmax = n * HS > N ? n * HS : N;
+        if (cmax <= b.nthr) {                                    // everything fits one chunk: the four arrays side by side
+            const int e = b.tid;
+            Jet2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (e < cnt[q]) v[q] = ja[off[q] + e];
+            b.sync();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (e < cnt[q]) da2[off[q] + e] = Dual(v[q].v, v[q].d);
+            b.sync();
+        } else {                                                 // array by array in layout order (a Dual lands below its Jet2)
+            for (int q = 0; q < 4; ++q)
+                for (int e0 = 0; e0 < cnt[q]; e0 += b.nthr) {
+                    const int e = e0 + b.tid;
+                    Jet2 v; if (e < cnt[q]) v = ja[off[q] + e];
+                    b.sync();
+                    if (e < cnt[q]) da2[off[q] + e] = Dual(v.v, v.d);
+                    b.sync();
+                }
+        }
         F::jacobian(b, th, n, L, da2, o);
     }
 
