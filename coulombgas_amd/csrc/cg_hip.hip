@@ -481,6 +481,7 @@ struct cg_ctx {
     bool fast = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* bounce = nullptr; size_t bounce_cap = 0;     // pinned staging buffer for large device-to-host results
     double* d_theta = nullptr;
     double* d_spk = nullptr;
     double* d_tab = nullptr;     // exp / log tables of cg_common.hpp
@@ -563,6 +564,21 @@ static int stage(cg_ctx* c, Arg& a) {
 }
 static int unstage(cg_ctx* c, Arg& a) {
     if (!a.user || c->ptr_mode == CG_PTR_DEVICE || !a.out) return CG_OK;
+    if (a.bytes >= ((size_t)1 << 20)) {
+        // Large results (Fisher matrices, score blocks) go through a pinned buffer: a device-to-host copy into pageable
+        // memory ran at ~1 GB/s on part of the pool (9 MB Fisher matrix: 10 ms), DMA into pinned memory + memcpy does not.
+        if (c->bounce_cap < a.bytes) {
+            if (c->bounce) { (void)hipHostFree(c->bounce); c->bounce = nullptr; c->bounce_cap = 0; }
+            if (hipHostMalloc(&c->bounce, a.bytes, hipHostMallocDefault) == hipSuccess) c->bounce_cap = a.bytes;
+            else { c->bounce = nullptr; (void)hipGetLastError(); }
+        }
+        if (c->bounce) {
+            CG_HIP(c, hipMemcpyAsync(c->bounce, a.dev, a.bytes, hipMemcpyDeviceToHost, c->stream));
+            CG_HIP(c, hipStreamSynchronize(c->stream));
+            memcpy(a.user, c->bounce, a.bytes);
+            return CG_OK;
+        }
+    }
     CG_HIP(c, hipMemcpyAsync(a.user, a.dev, a.bytes, hipMemcpyDeviceToHost, c->stream));
     return CG_OK;
 }
@@ -663,6 +679,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& ch : c->chunks) (void)hipFree(ch.p);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->bounce) (void)hipHostFree(c->bounce);
     if (c->d_scores) (void)hipFree(c->d_scores);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_spk) (void)hipFree(c->d_spk);
