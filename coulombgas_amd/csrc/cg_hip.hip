@@ -288,30 +288,34 @@ __global__ void __launch_bounds__(256) k_fisher(const double* __restrict__ S, in
     }
 }
 // mean over the batch of the complex scores (src/sr.py:70): out[2 p + c] = (1/B) sum_b S[b][p][c]; fixed summation order
-__global__ void __launch_bounds__(256) k_score_mean(const double* __restrict__ S, int B, int P2 /* 2 P */, double* __restrict__ out) {
+// Column sums of the resident score matrix over one slice of the batch (blockIdx.y): out[slice][c] = sum_{b in slice} S[b][c].
+// The slices are summed in fixed order by k_reduce_rows (deterministic), the 1/B of the mean is applied afterwards.
+__global__ void __launch_bounds__(256) k_score_mean(const double* __restrict__ S, int B, int P2 /* 2 P */, int chunk, double* __restrict__ out) {
     __shared__ double part[256];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
     double a = 0.0;
-    if (c < P2) for (int b = rg; b < B; b += 4) a += S[(size_t)b * P2 + c];
+    if (c < P2) for (int b = b0 + rg; b < b1; b += 4) a += S[(size_t)b * P2 + c];
     part[threadIdx.x] = a;
     __syncthreads();
-    if (rg == 0 && c < P2) out[c] = (part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]) / (double)B;
+    if (rg == 0 && c < P2) out[(size_t)blockIdx.y * P2 + c] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
 }
 
-// out[p] = sum_b ( w_re[b] Sre[b][p] + w_im[b] Sim[b][p] ): the theta-VJP from resident scores; fixed summation order
+// out[slice][p] = sum_{b in slice} ( w_re[b] Sre[b][p] + w_im[b] Sim[b][p] ): the theta-VJP from resident scores
 __global__ void __launch_bounds__(256) k_score_gemv(const double* __restrict__ S, const double* __restrict__ w_re,
-                                                    const double* __restrict__ w_im, int B, int P, double* __restrict__ out) {
+                                                    const double* __restrict__ w_im, int B, int P, int chunk, double* __restrict__ out) {
     __shared__ double part[256];
     const int p = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
     double a = 0.0;
     if (p < P)
-        for (int b = rg; b < B; b += 4) {
+        for (int b = b0 + rg; b < b1; b += 4) {
             const double* s = S + ((size_t)b * P + p) * 2;
             a += w_re[b] * s[0] + w_im[b] * s[1];
         }
     part[threadIdx.x] = a;
     __syncthreads();
-    if (rg == 0 && p < P) out[p] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+    if (rg == 0 && p < P) out[(size_t)blockIdx.y * P + p] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
 }
 
 __global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
@@ -1071,6 +1075,20 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     return finish(c);
 }
 
+// Batch reductions over the resident score matrix, sliced over the batch so that the whole chip streams it (one slice
+// per ~64 walkers, at most 64 slices), then summed in fixed order: mean over b (w_re == nullptr, count = 2P, scaled by 1/B)
+// or the weighted sum of cg_scores_vjp (count = P).
+static int score_reduce(cg_ctx* c, const double* S, const double* w_re, const double* w_im, int B, int count, double* out) {
+    const int nsl = std::max(1, std::min(64, (B + 63) / 64)), chunk = (B + nsl - 1) / nsl;
+    double* partial = (double*)arena_take(c, sizeof(double) * (size_t)nsl * count);
+    if (!partial) CG_FAIL(c, CG_ERR_HIP, "score reduction: workspace allocation failed");
+    if (w_re) hipLaunchKernelGGL(k_score_gemv, dim3((count + 63) / 64, nsl), dim3(256), 0, c->stream, S, w_re, w_im, B, count, chunk, partial);
+    else hipLaunchKernelGGL(k_score_mean, dim3((count + 63) / 64, nsl), dim3(256), 0, c->stream, S, B, count, chunk, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((count + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, nsl, count, out);
+    if (!w_re) hipLaunchKernelGGL(k_scale, dim3((count + 255) / 256), dim3(256), 0, c->stream, out, (size_t)count, 1.0 / (double)B);
+    return CG_OK;
+}
+
 static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
                    const double* w_im, double* g_theta, double* score, double* fisher = nullptr, double* smean = nullptr,
                    bool keep_scores = false) {
@@ -1135,7 +1153,7 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     if (fisher) {
         const int tiles = (P + 15) / 16;
         hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)asc.dev, B, P, (double*)afi.dev);
-        if (smean) hipLaunchKernelGGL(k_score_mean, dim3((2 * P + 63) / 64), dim3(256), 0, c->stream, (const double*)asc.dev, B, 2 * P, (double*)asm_.dev);
+        if (smean && (rc = score_reduce(c, (const double*)asc.dev, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
     }
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
@@ -1168,8 +1186,7 @@ int cg_scores_vjp(cg_ctx* c, const double* w_re, const double* w_im, double* g_t
     Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
     Arg* all[] = {&awr, &awi, &ag};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    hipLaunchKernelGGL(k_score_gemv, dim3((P + 63) / 64), dim3(256), 0, c->stream, (const double*)c->d_scores, (const double*)awr.dev,
-                       (const double*)awi.dev, B, P, (double*)ag.dev);
+    if ((rc = score_reduce(c, (const double*)c->d_scores, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
 }
@@ -1186,7 +1203,7 @@ int cg_scores_fisher(cg_ctx* c, double* fisher, double* score_mean) {
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
     const int tiles = (P + 15) / 16;
     hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)c->d_scores, B, P, (double*)afi.dev);
-    hipLaunchKernelGGL(k_score_mean, dim3((2 * P + 63) / 64), dim3(256), 0, c->stream, (const double*)c->d_scores, B, 2 * P, (double*)asm_.dev);
+    if ((rc = score_reduce(c, (const double*)c->d_scores, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
 }

@@ -256,12 +256,20 @@ class Engine:
         check(lib().cg_quantum_score(self._ctx, _p(xb), _p(s), B, _p(sc)), self._ctx)
         return (sc[..., 0] + 1j * sc[..., 1]).reshape(lead + (self.P,))
 
-    def quantum_fisher(self, x, state_idx):
-        """fishers_fn of src/sr.py:62-80 for this device: (Re(S^H S)/B (P,P), mean_b S (P,) complex)."""
+    def quantum_fisher(self, x, state_idx, reuse_out=False):
+        """fishers_fn of src/sr.py:62-80 for this device: (Re(S^H S)/B (P,P), mean_b S (P,) complex).
+        reuse_out: return the engine's own (P,P) buffer, overwritten by the next such call (an optimisation loop consumes
+        the matrix at once; a fresh 9 MB array per epoch costs its page faults again every time)."""
         xb, _ = self._xb(x)
         B = xb.shape[0]
         s = self._sb(state_idx, B)
-        F = np.empty((self.P, self.P)); sm = np.empty((self.P, 2))
+        if reuse_out:
+            if getattr(self, "_fisher_out", None) is None:
+                self._fisher_out = np.empty((self.P, self.P))
+            F = self._fisher_out
+        else:
+            F = np.empty((self.P, self.P))
+        sm = np.empty((self.P, 2))
         if self._mode == _lib.CG_PTR_HOST and self._scores_ready(xb, s):
             check(lib().cg_scores_fisher(self._ctx, _p(F), _p(sm)), self._ctx)
         else:

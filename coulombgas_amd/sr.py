@@ -101,6 +101,12 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
             cs = _ravel_batched(classical_score_fn(params_van, state_indices))
             cf = eng.fisher_real(cs) if hasattr(eng, "fisher_real") else cs.T.dot(cs) / cs.shape[0]
             classical_fisher = cm.pmean(cf)
+        if getattr(cm, "world", 1) == 1:             # nothing to average: hand the engine's matrix on as it is
+            try:
+                qf, qmean = eng.quantum_fisher(x, state_indices, reuse_out=True)
+            except TypeError:                        # an engine without the buffer option
+                qf, qmean = eng.quantum_fisher(x, state_indices)
+            return classical_fisher, qf, qmean
         qf, qmean = eng.quantum_fisher(x, state_indices)
         packed = cm.pmean(np.concatenate([qf.reshape(-1), qmean.real, qmean.imag]))      # one all-reduce
         P = qmean.shape[0]
