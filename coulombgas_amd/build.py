@@ -28,12 +28,35 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "coulombgas.h")]
 
 
+HIP_UNITS = ("cg_hip.hip", "cg_k_sampler.hip", "cg_k_derivs.hip", "cg_k_generic.hip")
+HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+
+
+def _compile_units(objdir, flags, force=False):
+    """hipcc -c of every translation unit, in parallel (one process per unit); returns the object files."""
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [f for f in hip_sources() if not f.endswith(".hip")]
+    jobs, objs = [], []
+    for u in HIP_UNITS:
+        src, obj = os.path.join(CSRC, u), os.path.join(objdir, u[:-4] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, hdrs + [src]):
+            cmd = [hipcc] + HIP_FLAGS + list(flags) + ["-c", "-o", obj, src]
+            print("+", " ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    return objs
+
+
 def build_hip(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     if force or _newer(HIP_LIB, hip_sources()):
+        objs = _compile_units(os.path.join(ROOT, "build", "hip"), [], force)
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC",
-              "-o", HIP_LIB, os.path.join(CSRC, "cg_hip.hip"), "-ldl"])
+        _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs + ["-ldl"])
     return HIP_LIB
 
 
@@ -41,9 +64,9 @@ def build_diag(name, flags):
     """Diagnostic A/B builds of the same ABI (tools/): lib/diag/lib<name>.so, selected with COULOMBGAS_HIP_LIB."""
     out = os.path.join(LIBDIR, "diag", "lib%s.so" % name)
     os.makedirs(os.path.dirname(out), exist_ok=True)
+    objs = _compile_units(os.path.join(ROOT, "build", "diag_" + name), flags, True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    _run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC"] + list(flags) +
-         ["-o", out, os.path.join(CSRC, "cg_hip.hip"), "-ldl"])
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out
 
 

@@ -1,0 +1,334 @@
+// cg_k_derivs.hip -- grad / Laplacian of log Psi (cg_lap.hpp), theta-VJP and per-sample scores (cg_derivs.hpp), the score
+// reductions and the quantum Fisher matrix + their entry points.
+#include "cg_host.hpp"
+#include "cg_derivs.hpp"
+#include "cg_lap.hpp"
+
+#ifndef CG_LAP_LDS_BYTES
+#define CG_LAP_LDS_BYTES (80 * 1024)
+#endif
+
+// grad / Laplacian of log Psi w.r.t. x (cg_lap.hpp): one workgroup per walker, persistent over the batch.
+// AL: every array of the kernel lives in LDS (the BASELINE size n = 13: 78 KB, two workgroups per CU); otherwise the
+// blocks that do not fit the budget use the per-workgroup HBM workspace.  Register budget: 2 waves per SIMD.
+template <int D, int HS, int HT, bool AL>
+__global__ void __launch_bounds__(256, 2) k_grad_lap2(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
+                           const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
+                           double* ws, typename CgLap<D, HS, HT>::Lay lay) {
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    const int n = m.n, N = n * D;
+    const double* th = theta;
+    if (lay.th_lds) {                    // per-lane weight reads from LDS instead of the vector L1
+        double* th_l = lds + lay.th;
+        for (int e = b.tid; e < CgFast<D, HS, HT>::NPARAM; e += b.nthr) th_l[e] = theta[e];
+        th = th_l;
+    }
+    __syncthreads();
+    CG_STAMP_INIT
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        CgLap<D, HS, HT>::template grad_laplacian<AL>(b, th, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
+                                                      v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
+                                                      lds, ws + (size_t)blockIdx.x * lay.ws_total, lay);
+        b.sync();
+    }
+    CG_STAMP_FLUSH
+}
+
+template <int D, int HS, int HT>
+__global__ void __launch_bounds__(256, CG_DERIV_WAVES_OF(D)) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
+                            const double* __restrict__ w_re, const double* __restrict__ w_im,
+                            double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
+                            double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    const int n = m.n, N = n * D;
+    constexpr int P = CgFast<D, HS, HT>::NPARAM;
+    double* gacc = partial ? partial + (size_t)blockIdx.x * P : nullptr;
+    if (gacc) for (int e = b.tid; e < P; e += b.nthr) gacc[e] = 0.0;
+    b.sync();
+    for (int w = blockIdx.x; w < B; w += gridDim.x) {
+        CgDerivs<D, HS, HT>::param_vjp(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L,
+                                       w_re ? w_re[w] : 1.0, w_im ? w_im[w] : 0.0, gacc,
+                                       score ? score + (size_t)w * P * 2 : nullptr,
+                                       ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
+        b.sync();
+    }
+}
+
+// deterministic second-stage reduction of per-workgroup partial gradients: out[p] = sum_g partial[g][p]
+__global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int P, double* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += partial[(size_t)r * P + p];
+    out[p] = a;
+}
+
+// Quantum Fisher matrix of stochastic reconfiguration (src/sr.py:74-76):  F[p][q] = (1/B) sum_b Re( conj(S[b][p]) S[b][q] )
+// = (1/B) sum_b ( Sr[b][p] Sr[b][q] + Si[b][p] Si[b][q] ),  S = per-sample scores (B x P, complex interleaved).
+// One wave per 16 x 16 tile of the upper triangle (mirrored on store); the batch axis is the K of v_mfma_f64_16x16x4.
+__global__ void __launch_bounds__(256) k_fisher(const double* __restrict__ S, int B, int P, double* __restrict__ F) {
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles = (P + 15) >> 4;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= tiles * tiles) return;
+    const int ti = tile / tiles, tj = tile - ti * tiles;
+    if (tj < ti) return;
+    const int col = lane & 15, kq = lane >> 4;
+    const int p = 16 * ti + col, q = 16 * tj + col;
+    const bool pok = p < P, qok = q < P;
+    d4_t acc = {0, 0, 0, 0};
+    for (int b1 = 0; b1 < B; b1 += 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                 // four independent load groups in flight per trip
+            const int b = b1 + 4 * u + kq;
+            const bool bok = b < B;
+            const double* sa = S + ((size_t)b * P + p) * 2;
+            const double* sb = S + ((size_t)b * P + q) * 2;
+            const double a_re = (bok && pok) ? sa[0] : 0.0, a_im = (bok && pok) ? sa[1] : 0.0;
+            const double b_re = (bok && qok) ? sb[0] : 0.0, b_im = (bok && qok) ? sb[1] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, b_re, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, b_im, acc, 0, 0, 0);
+        }
+    }
+    const double rb = 1.0 / (double)B;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pr = 16 * ti + kq + 4 * r;
+        if (pr < P && qok) {
+            const double v = acc[r] * rb;
+            F[(size_t)pr * P + q] = v;
+            if (ti != tj) F[(size_t)q * P + pr] = v;
+        }
+    }
+}
+// mean over the batch of the complex scores (src/sr.py:70): out[2 p + c] = (1/B) sum_b S[b][p][c]; fixed summation order
+// Column sums of the resident score matrix over one slice of the batch (blockIdx.y): out[slice][c] = sum_{b in slice} S[b][c].
+// The slices are summed in fixed order by k_reduce_rows (deterministic), the 1/B of the mean is applied afterwards.
+__global__ void __launch_bounds__(256) k_score_mean(const double* __restrict__ S, int B, int P2 /* 2 P */, int chunk, double* __restrict__ out) {
+    __shared__ double part[256];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
+    double a = 0.0;
+    if (c < P2) for (int b = b0 + rg; b < b1; b += 4) a += S[(size_t)b * P2 + c];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && c < P2) out[(size_t)blockIdx.y * P2 + c] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+}
+
+// out[slice][p] = sum_{b in slice} ( w_re[b] Sre[b][p] + w_im[b] Sim[b][p] ): the theta-VJP from resident scores
+__global__ void __launch_bounds__(256) k_score_gemv(const double* __restrict__ S, const double* __restrict__ w_re,
+                                                    const double* __restrict__ w_im, int B, int P, int chunk, double* __restrict__ out) {
+    __shared__ double part[256];
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
+    double a = 0.0;
+    if (p < P)
+        for (int b = b0 + rg; b < b1; b += 4) {
+            const double* s = S + ((size_t)b * P + p) * 2;
+            a += w_re[b] * s[0] + w_im[b] * s[1];
+        }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && p < P) out[(size_t)blockIdx.y * P + p] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+}
+
+
+
+extern "C" {
+
+int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, int mode, const double* v,
+                      double* grad, double* lap) {
+    int rc = check_ready(c, "cg_grad_laplacian", B); if (rc) return rc;
+    if (mode < 0 || mode > 2) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: mode %d", mode);
+    if (mode != CG_LAP_EXACT && !v) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: Hutchinson modes need v");
+    if (B == 0) return CG_OK;
+    if (!x || !sidx || !grad || !lap) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian: NULL argument");
+    const int n = c->n, N = n * c->dim;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_grad_laplacian: arena");
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg av{(void*)v, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg ag{grad, nullptr, sizeof(double) * (size_t)B * N * 2, false, true};
+    Arg al{lap, nullptr, sizeof(double) * (size_t)B * 2, false, true};
+    Arg* all[] = {&ax, &as, &av, &ag, &al};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int nt = 256;
+    const int grid = std::min(B, c->cu_count * 2 * (c->fast ? 2 : CG_DERIV_WAVES));
+    if (!c->fast) {
+        if ((rc = cg_gen_run_grad_lap(c, grid, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev,
+                                      (double*)al.dev))) return rc;
+        for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+        return finish(c);
+    }
+    const CgDev m = make_dev(c);
+    bool launched = false;
+    // LDS budget: half a CU (two workgroups of 256 threads per CU = 2 waves per SIMD)
+    const size_t lds_budget = (size_t)CG_LAP_LDS_BYTES / sizeof(double) - CG_TAB_DOUBLES;
+#define CG_X(D, HS, HT)                                                                                              \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
+        const auto dl = CgLap<D, HS, HT>::layout(n, nt, mode, lds_budget);                                          \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)dl.lds_total);                                \
+        if ((rc = ensure_ws(c, sizeof(double) * ((size_t)dl.ws_total * grid + 8)))) return rc;                      \
+        if (dl.all_lds) {                                                                                           \
+            if ((rc = set_lds(c, k_grad_lap2<D, HS, HT, true>, lds))) return rc;                                    \
+            hipLaunchKernelGGL((k_grad_lap2<D, HS, HT, true>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
+                               (double*)c->ws, dl);                                                                 \
+        } else {                                                                                                    \
+            if ((rc = set_lds(c, k_grad_lap2<D, HS, HT, false>, lds))) return rc;                                   \
+            hipLaunchKernelGGL((k_grad_lap2<D, HS, HT, false>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
+                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
+                               (double*)c->ws, dl);                                                                 \
+        }                                                                                                           \
+        launched = true;                                                                                            \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_grad_laplacian: configuration not instantiated");
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+
+// Batch reductions over the resident score matrix, sliced over the batch so that the whole chip streams it (one slice
+// per ~64 walkers, at most 64 slices), then summed in fixed order: mean over b (w_re == nullptr, count = 2P, scaled by 1/B)
+// or the weighted sum of cg_scores_vjp (count = P).
+static int score_reduce(cg_ctx* c, const double* S, const double* w_re, const double* w_im, int B, int count, double* out) {
+    const int nsl = std::max(1, std::min(64, (B + 63) / 64)), chunk = (B + nsl - 1) / nsl;
+    double* partial = (double*)arena_take(c, sizeof(double) * (size_t)nsl * count);
+    if (!partial) CG_FAIL(c, CG_ERR_HIP, "score reduction: workspace allocation failed");
+    if (w_re) hipLaunchKernelGGL(k_score_gemv, dim3((count + 63) / 64, nsl), dim3(256), 0, c->stream, S, w_re, w_im, B, count, chunk, partial);
+    else hipLaunchKernelGGL(k_score_mean, dim3((count + 63) / 64, nsl), dim3(256), 0, c->stream, S, B, count, chunk, partial);
+    hipLaunchKernelGGL(k_reduce_rows, dim3((count + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, nsl, count, out);
+    if (!w_re) return cg_scale_dev(c, out, (size_t)count, 1.0 / (double)B);
+    return CG_OK;
+}
+
+static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* sidx, int B, const double* w_re,
+                   const double* w_im, double* g_theta, double* score, double* fisher = nullptr, double* smean = nullptr,
+                   bool keep_scores = false) {
+    int rc = check_ready(c, fn, B); if (rc) return rc;
+    const int n = c->n, N = n * c->dim, P = c->P;
+    if (B == 0) {
+        if (g_theta && c->ptr_mode == CG_PTR_HOST) memset(g_theta, 0, sizeof(double) * P);
+        else if (g_theta) CG_HIP(c, hipMemsetAsync(g_theta, 0, sizeof(double) * P, c->stream));
+        return CG_OK;
+    }
+    if (!x || !sidx) CG_FAIL(c, CG_ERR_ARG, "%s: NULL argument", fn);
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "%s: arena", fn);
+    Arg ax{(void*)x, nullptr, sizeof(double) * (size_t)B * N, true, false};
+    Arg as{(void*)sidx, nullptr, sizeof(int32_t) * (size_t)B * n, true, false};
+    Arg awr{(void*)w_re, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg awi{(void*)w_im, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
+    Arg asc{score, nullptr, sizeof(double) * (size_t)B * P * 2, false, true};
+    Arg afi{fisher, nullptr, sizeof(double) * (size_t)P * P, false, true};
+    Arg asm_{smean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
+    Arg* all[] = {&ax, &as, &awr, &awi, &ag, &asc, &afi, &asm_};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    if ((fisher || keep_scores) && !asc.dev) {        // the scores stay on the device, in the context's resident buffer
+        if (c->scores_cap < asc.bytes) {
+            if (c->d_scores) { CG_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_scores); c->d_scores = nullptr; c->scores_cap = 0; }
+            if (hipMalloc((void**)&c->d_scores, asc.bytes) != hipSuccess)
+                CG_FAIL(c, CG_ERR_HIP, "%s: %zu bytes for the per-sample scores could not be allocated", fn, asc.bytes);
+            c->scores_cap = asc.bytes;
+        }
+        asc.dev = c->d_scores; c->scores_B = B;
+    }
+    const int nt = 256;
+    const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
+    double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
+    if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
+    const CgDev m = make_dev(c);
+    bool launched = false;
+    if (!c->fast) {       // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
+        if ((rc = cg_gen_run_param_vjp(c, grid, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev,
+                                       partial, (double*)asc.dev))) return rc;
+        launched = true;
+    }
+#define CG_X(D, HS, HT)                                                                                               \
+    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
+        const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \
+        const auto dl = CgDerivs<D, HS, HT>::layout(n, nt);                                                          \
+        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::vjp_lds_doubles(dl)); \
+        if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
+        if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
+        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
+                           (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
+                           (double*)asc.dev, (double*)c->ws, wsw, dl);                                               \
+        launched = true;                                                                                             \
+    }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
+    if (g_theta)
+        hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
+    if (fisher) {
+        const int tiles = (P + 15) / 16;
+        hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)asc.dev, B, P, (double*)afi.dev);
+        if (smean && (rc = score_reduce(c, (const double*)asc.dev, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
+    }
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+
+int cg_param_vjp(cg_ctx* c, const double* x, const int32_t* sidx, int B, const double* w_re, const double* w_im, double* g_theta) {
+    if (c && !g_theta) CG_FAIL(c, CG_ERR_ARG, "cg_param_vjp: g_theta is NULL");
+    if (c && (!w_re || !w_im) && B > 0) CG_FAIL(c, CG_ERR_ARG, "cg_param_vjp: weights are NULL");
+    return run_vjp(c, "cg_param_vjp", x, sidx, B, w_re, w_im, g_theta, nullptr);
+}
+int cg_quantum_score(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* score) {
+    if (c && !score) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_score: score is NULL");
+    return run_vjp(c, "cg_quantum_score", x, sidx, B, nullptr, nullptr, nullptr, score);
+}
+/* Resident per-sample scores: computed once per (x, state_idx, theta), then reused for the theta-VJPs of the loss
+ * (weights 2 Re/Im E_clip / B and 2 / B, main.py:278) and for the Fisher matrix -- 2 reverse sweeps instead of 6. */
+int cg_scores_compute(cg_ctx* c, const double* x, const int32_t* sidx, int B) {
+    if (c && B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_scores_compute: empty batch");
+    return run_vjp(c, "cg_scores_compute", x, sidx, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, true);
+}
+int cg_scores_vjp(cg_ctx* c, const double* w_re, const double* w_im, double* g_theta) {
+    if (!c) return CG_ERR_ARG;
+    if (!c->d_scores || c->scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_scores_vjp: cg_scores_compute has not been called");
+    if (!w_re || !w_im || !g_theta) CG_FAIL(c, CG_ERR_ARG, "cg_scores_vjp: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->scores_B, P = c->P;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_scores_vjp: arena");
+    Arg awr{(void*)w_re, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg awi{(void*)w_im, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ag{g_theta, nullptr, sizeof(double) * (size_t)P, false, true};
+    Arg* all[] = {&awr, &awi, &ag};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    if ((rc = score_reduce(c, (const double*)c->d_scores, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_scores_fisher(cg_ctx* c, double* fisher, double* score_mean) {
+    if (!c) return CG_ERR_ARG;
+    if (!c->d_scores || c->scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_scores_fisher: cg_scores_compute has not been called");
+    if (!fisher || !score_mean) CG_FAIL(c, CG_ERR_ARG, "cg_scores_fisher: NULL output");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->scores_B, P = c->P;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_scores_fisher: arena");
+    Arg afi{fisher, nullptr, sizeof(double) * (size_t)P * P, false, true};
+    Arg asm_{score_mean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
+    Arg* all[] = {&afi, &asm_};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int tiles = (P + 15) / 16;
+    hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)c->d_scores, B, P, (double*)afi.dev);
+    if ((rc = score_reduce(c, (const double*)c->d_scores, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_quantum_fisher(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* fisher, double* score_mean) {
+    if (c && (!fisher || !score_mean)) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: NULL output");
+    if (c && B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: empty batch");
+    return run_vjp(c, "cg_quantum_fisher", x, sidx, B, nullptr, nullptr, nullptr, nullptr, fisher, score_mean);
+}
+
+}  // extern "C"

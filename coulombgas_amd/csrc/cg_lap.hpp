@@ -1,0 +1,814 @@
+// cg_lap.hpp -- grad_x log Psi and laplacian_x log Psi of the depth-2 flow wave function, second generation.
+//
+// Reference: make_logpsi_grad_laplacian, src/logpsi.py:55-172 (exact :77-106, Hutchinson :112-132, Hutchinson-split
+// :134-164 -- the variant main.py:255-256 selects for every shipped run).  The reference nests AD transforms; the first
+// generation of this kernel (cg_derivs.hpp) pushed one second-order jet per coordinate direction through the whole flow +
+// Jacobian assembly (n d + 1 passes).  Here every piece is taken in the cheapest exact form:
+//
+//   grad_x log Psi      = J^T g  +  grad_x 1/2 log|det J|            g_ia = d log phi / d z_ia = T^a_ii   (App. A.3)
+//                         the second term by ONE reverse sweep through the structured Jacobian assembly with the
+//                         cotangent Jbar = 1/2 J^-T  (what jax.grad(logjacdet) does, src/logpsi.py:137-138)
+//   lap_x log phi(z(x)) = tr(J^T H J) + g . lap_x z                  H = d2 log phi / dz dz (closed form, App. A.3)
+//                         lap_x z by a forward-Laplacian pass through the flow: every hidden unit carries its value, the
+//                         squared norm of its x-gradient and its Laplacian; for the depth-2 net only the last layer's
+//                         pre-activations need their dense x-gradient (n HS x n d), which is a small GEMM
+//   v^T hess(1/2 log|det J|) v : one second-order jet pass along the probe v (Hutchinson modes), or n d basis passes
+//                         (exact mode; third derivatives of the flow are inherently that expensive)
+//
+// Modes (include/coulombgas.h): 0 exact, 1 Hutchinson (v^T hess(log Psi) v), 2 Hutchinson-split.
+//
+// Memory: one workgroup per walker.  The arrays are grouped into three blocks (Lay), each placed on the host either in
+// LDS or in the per-workgroup HBM workspace.  When everything fits the LDS budget the kernel is instantiated with
+// AL = true and every access is a ds_ instruction.
+#pragma once
+#include "cg_flow_fast.hpp"
+
+template <int D, int HS, int HT>
+struct CgLap {
+    using F = CgFast<D, HS, HT>;
+    static constexpr int P = F::P;
+    static constexpr int NP = F::NPARAM;
+    static constexpr int HM = HT > P ? HT : P;
+
+    // Three blocks, each wholly in LDS or wholly in the per-workgroup HBM workspace (decided on the host):
+    //   P  persistent: x, g, xbar, J^-1 (and T^a, K^ab in mode 1: the probe pass needs them)
+    //   A  set-up, Slater part, reverse sweep, forward Laplacian (sub-phases overlay each other inside the block)
+    //   B  jet passes; overlays A (the primal arena is dead by then)
+    // Array offsets are doubles relative to their block.
+    struct Lay {
+        CgFastLds o;        // primal + Jacobian arena inside A, ordered by lifetime (R1 | R3 | R2, see layout())
+        CgFastLds oj;       // Jet2 arena of the directional passes (aliased sampler layout) inside B
+        int all_lds;        // 1: every block is in LDS
+        int th_lds, th;     // 1: theta is copied to LDS at doubles offset th
+        int P_lds, A_lds, B_lds;             // block placement
+        unsigned P_off, A_off, B_off;        // block base (doubles) in its pool
+        // P
+        int red, x, gz, xbar, Jinv, Ta, Kd, TaKd_in_P;
+        // A
+        int da, Jc, Dc, Dinv, perm, C;
+        int Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, u2b, u1b, s1b, m1b, gbb, su2, m0b, rbar;
+        int Lm0, gu1, Ls1, Lm1, Lgb, Am, Hk, SQ, Er, Su2, Ls2;
+        // B
+        int ja, xj, M, M_in_arena;
+        unsigned lds_total, ws_total;      // doubles
+    };
+
+    // lds_budget_doubles: LDS doubles available to this kernel's arrays (excluding the exp/log tables).
+    static Lay layout(int n, int nthr, int mode, size_t lds_budget_doubles, bool theta_in_lds = true) {
+        const size_t N = (size_t)n * D, NN = N * N, nn2 = 2 * (size_t)n * n;
+        Lay l; memset(&l, 0, sizeof(l));
+        {   // jet arena: the aliased sampler layout (cg_fast_layout(alias = true)) with the weight scratch sized in doubles
+            CgFastLds& j = l.oj; int t = 0;
+            auto tk = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
+            j.sh = tk(n * D); j.ch = tk(n * D); j.z = tk(n * D); j.sg1 = tk(n * HS); j.sg2 = tk(n * HS);
+            j.perm = tk(2); j.wt = tk((HT * (P + 1) + 2) / 3 + 1);        // HT (P + 1) doubles inside an arena of Jet2 elements
+            const int base = t;
+            j.m0 = tk(n * P); j.s1 = tk(n * HS); j.m1 = tk(n * HT); j.gbar = tk(HS); j.cb = tk(HS); j.s2 = tk(n * HS);
+            const int end_primal = t;
+            t = base;
+            j.V = tk(n * (HT * D + 2)); j.Bm = tk(n * (HS * D + 2)); j.Up = tk(n * D * P); j.G = tk(n * (HS * D + 2));
+            const int end_jac = t;
+            t = end_primal > end_jac ? end_primal : end_jac;
+            j.J = tk(n * D * n * D);
+            j.U = j.J;                                                    // U is dead once Up is formed
+            if (n * D * HS > n * D * n * D) j.U = tk(n * D * HS);
+            j.Dm = j.J; j.lus = base; j.wave_lu = 0;
+            j.total = t;
+        }
+        auto ev = [](size_t c) { return (c + 1) & ~(size_t)1; };
+        size_t t = 0;
+        auto take = [&](size_t c) { const size_t r = t; t += ev(c); return (int)r; };
+        // ---- P
+        l.red = take(8 * (size_t)(nthr / 64 + 1)); l.x = take(N); l.gz = take(2 * N); l.xbar = take(N); l.Jinv = take(NN);
+        l.TaKd_in_P = mode == 1 ? 1 : 0;
+        if (l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
+        const size_t P_size = t;
+        // ---- A: arena R1 (alive through the whole of A)
+        t = 0;
+        l.da = 0;
+        CgFastLds& o = l.o;
+        o.sh = take(N); o.ch = take(N); o.z = take(N); o.sg1 = take((size_t)n * HS); o.sg2 = take((size_t)n * HS);
+        o.perm = take(2); o.wt = take(HT * (P + 1) + HS * D);
+        o.U = take(N * HS); o.V = take((size_t)n * (HT * D + 2)); o.Bm = take((size_t)n * (HS * D + 2)); o.Up = take(N * P);
+        o.G = take((size_t)n * (HS * D + 2));
+        if (!l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
+        const size_t A1 = t;
+        // R3: J, Slater matrix (dead after the Slater part);  R2: primal temporaries;  then the set-up scratch
+        o.J = take(NN); o.Dm = take(nn2); o.lus = take(2);
+        const size_t A2 = t;
+        o.m0 = take((size_t)n * P); o.s1 = take((size_t)n * HS); o.m1 = take((size_t)n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take((size_t)n * HS);
+        o.total = (int)t; o.wave_lu = 0;
+        l.Jc = take(NN); l.Dc = take(nn2); l.Dinv = take(nn2); l.perm = take(N + 42);
+        size_t A_size = t;
+        t = A2; l.C = take(NN); A_size = t > A_size ? t : A_size;
+        t = A1;
+        l.Jhat = take(NN);
+        l.Upb = take(N * P); l.Vb = take(N * HT); l.Bb = take(N * HS); l.Gb = take((size_t)n * HS * D);
+        l.sg1b = take((size_t)n * HS); l.sg2b = take((size_t)n * HS); l.Ub = take(N * HS); l.Rb = take(N * HS);
+        l.u2b = take((size_t)n * HS); l.u1b = take((size_t)n * HS); l.s1b = take((size_t)n * HS); l.m1b = take((size_t)n * HT);
+        l.gbb = take(HS); l.su2 = take(HS); l.m0b = take((size_t)n * P); l.rbar = take((size_t)n * n * D);
+        A_size = t > A_size ? t : A_size;
+        t = A1;
+        l.Lm0 = take((size_t)n * P); l.gu1 = take((size_t)n * HS); l.Ls1 = take((size_t)n * HS); l.Lm1 = take((size_t)n * HT);
+        l.Lgb = take(HS); l.Am = take((size_t)n * HS * P); l.Hk = take((size_t)n * HS * D);
+        l.SQ = take((size_t)n * HT * D); l.Er = take((size_t)n * HS * D); l.Su2 = take((size_t)n * HS); l.Ls2 = take((size_t)n * HS);
+        A_size = t > A_size ? t : A_size;
+        // ---- B
+        t = 0;
+        l.xj = take(3 * N); l.ja = take(3 * (size_t)l.oj.total);
+        // M = J^-1 J' (N x N doubles) fits the per-particle factor slots of the jet arena, dead once its J is assembled
+        l.M_in_arena = 3 * (size_t)(l.oj.J - l.oj.m0) >= NN ? 1 : 0;
+        l.M = l.M_in_arena ? l.ja + 3 * l.oj.m0 : take(NN);
+        const size_t B_size = t;
+        // ---- placement
+        const size_t AB = A_size > B_size ? A_size : B_size;
+        size_t lds = 0, ws = 0;
+        auto place = [&](size_t sz, int& in_lds, unsigned& off) {
+            if (lds + sz <= lds_budget_doubles) { in_lds = 1; off = (unsigned)lds; lds += sz; }
+            else { in_lds = 0; off = (unsigned)ws; ws += sz; }
+        };
+        place(P_size, l.P_lds, l.P_off);
+        if (lds + AB <= lds_budget_doubles) { l.A_lds = l.B_lds = 1; l.A_off = l.B_off = (unsigned)lds; lds += AB; }
+        else if (A_size <= B_size) {          // the larger block goes to the workspace; the smaller may still fit
+            l.B_lds = 0; l.B_off = (unsigned)ws; ws += B_size;
+            place(A_size, l.A_lds, l.A_off);
+        } else {
+            l.A_lds = 0; l.A_off = (unsigned)ws; ws += A_size;
+            place(B_size, l.B_lds, l.B_off);
+        }
+        l.all_lds = (l.P_lds && l.A_lds && l.B_lds) ? 1 : 0;
+        l.th_lds = 0; l.th = 0;
+        if (theta_in_lds && lds + ev(NP) <= lds_budget_doubles) { l.th = (int)lds; lds += ev(NP); l.th_lds = 1; }
+        l.lds_total = (unsigned)lds; l.ws_total = (unsigned)ws;
+        return l;
+    }
+
+    // block base pointers of one workgroup
+    template <bool AL>
+    struct Mem {
+        double *p, *a, *b;
+        CG_DEVI Mem(double* lds, double* ws, const Lay& l) {
+            if (AL) { p = lds + l.P_off; a = lds + l.A_off; b = lds + l.B_off; }
+            else {
+                p = (l.P_lds ? lds : ws) + l.P_off; a = (l.A_lds ? lds : ws) + l.A_off; b = (l.B_lds ? lds : ws) + l.B_off;
+            }
+        }
+    };
+
+    struct TCol { double tc[D], ts[D], td[D], rdel; };
+    static CG_DEVI void tcols(const typename F::PairF& pf, double c1, double c2c, TCol& t) {
+        t.rdel = 1.0 / pf.del;
+#pragma unroll
+        for (int bb = 0; bb < D; ++bb) { t.tc[bb] = -c1 * pf.s2[bb]; t.ts[bb] = c1 * pf.c2[bb]; t.td[bb] = c2c * pf.s2[bb] * t.rdel; }
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // set-up: z, J (kept), J^-1, D, D^-1 -> g, T^a, diag K^ab
+    // ------------------------------------------------------------------------------------------------------
+    template <bool AL>
+    static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
+                              const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                              const Mem<AL>& mem, const Lay& l) {
+        const int N = n * D;
+        const CgFastLds& o = l.o;
+        double* da = mem.a + l.da; double* x = mem.p + l.x;
+        for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
+        b.sync();
+        F::primal(b, th, (const double*)x, n, L, da, o);
+        F::jacobian(b, th, n, L, da, o);
+        double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
+        int* perm = (int*)(mem.a + l.perm);
+        for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+        b.sync();
+        (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+        F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+        for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+        b.sync();
+        double la, ar;
+        cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+        const double* Dm = da + o.Dm;
+        double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd; double* gz = mem.p + l.gz;
+        for (int e = b.tid; e < D * n * n; e += b.nthr) {            // T^a = D diag(i k^a) D^-1
+            const int a = e / (n * n), r = e - a * n * n, i = r / n, q = r - i * n;
+            double re = 0, im = 0;
+            for (int j = 0; j < n; ++j) {
+                const double ka = spk[(size_t)sidx[j] * D + a];
+                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + q)], Dinv[2 * (j * n + q) + 1]});
+                re += -ka * p.im; im += ka * p.re;
+            }
+            Ta[2 * e] = re; Ta[2 * e + 1] = im;
+            if (i == q) { gz[2 * (i * D + a)] = re; gz[2 * (i * D + a) + 1] = im; }   // g_ia = T^a_ii
+        }
+        for (int e = b.tid; e < D * D * n; e += b.nthr) {            // diag of K^ab = D diag(-k^a k^b) D^-1
+            const int a = e / (D * n), r = e - a * D * n, bb = r / n, i = r - bb * n;
+            double re = 0, im = 0;
+            for (int j = 0; j < n; ++j) {
+                const double kk = -spk[(size_t)sidx[j] * D + a] * spk[(size_t)sidx[j] * D + bb];
+                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
+                re += kk * p.re; im += kk * p.im;
+            }
+            Kd[2 * e] = re; Kd[2 * e + 1] = im;
+        }
+        b.sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // tr(J^T H J) with H the Hessian of log phi in z:  H_(ia),(lb) = delta_il K^ab_ii - T^a_il T^b_li
+    //   = sum_i sum_ab C_(ia),(ib) K^ab_ii - sum_il sum_ab C_(ia),(lb) T^a_il T^b_li ,   C = J J^T
+    // and the first part of the gradient, grad_e = (J^T g)_e (the caller adds xbar after the reverse sweep).  Returns the two partial sums of this thread in (p_re, p_im).
+    // ------------------------------------------------------------------------------------------------------
+    template <bool AL>
+    static CG_DEVI void slater_part(const CgBlk& b, int n, const Mem<AL>& mem, const Lay& l, bool want_lap,
+                                    double* __restrict__ grad /*N x 2, global*/, double& p_re, double& p_im) {
+        const int N = n * D;
+        const double* J = mem.a + l.da + l.o.J; const double* gz = mem.p + l.gz;
+        const double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; const double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd;
+        double* C = mem.a + l.C;
+        for (int e = b.tid; e < N; e += b.nthr) {
+            double re = 0, im = 0;
+            for (int al = 0; al < N; ++al) { const double j = J[al * N + e]; re += gz[2 * al] * j; im += gz[2 * al + 1] * j; }
+            grad[2 * e] = re; grad[2 * e + 1] = im;
+        }
+        p_re = 0; p_im = 0;
+        if (!want_lap) return;
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int al = e / N, be = e - al * N;
+            if (be < al) continue;
+            double c = 0;
+            for (int k = 0; k < N; ++k) c += J[al * N + k] * J[be * N + k];
+            C[al * N + be] = c; C[be * N + al] = c;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * D * D; e += b.nthr) {
+            const int i = e / (D * D), r = e - i * D * D, a = r / D, bb = r - a * D;
+            const double c = C[(i * D + a) * N + i * D + bb];
+            p_re += c * Kd[2 * ((a * D + bb) * n + i)]; p_im += c * Kd[2 * ((a * D + bb) * n + i) + 1];
+        }
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = e / n, q = e - i * n;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double c = C[(i * D + a) * N + q * D + bb];
+                    const CgCplx t1 = {Ta[2 * ((a * n + i) * n + q)], Ta[2 * ((a * n + i) * n + q) + 1]};
+                    const CgCplx t2 = {Ta[2 * ((bb * n + q) * n + i)], Ta[2 * ((bb * n + q) * n + i) + 1]};
+                    const CgCplx pr = cmul(t1, t2);
+                    p_re -= c * pr.re; p_im -= c * pr.im;
+                }
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // xbar = grad_x 1/2 log|det J(x)|: reverse sweep of CgFast::primal / jacobian with Jbar = 1/2 J^-T, zbar = 0.
+    // Same adjoint chain as CgDerivs::reverse (theta-gradient), continued down to the pair features and x.
+    // ------------------------------------------------------------------------------------------------------
+    template <bool AL>
+    static CG_DEVI void reverse_x(const CgBlk& b, const double* __restrict__ th, int n, double L, const Mem<AL>& mem, const Lay& l) {
+        const int N = n * D;
+        const CgFastLds& o = l.o;
+        const double* da = mem.a + l.da;
+        const double *sh = da + o.sh, *ch = da + o.ch, *sg1 = da + o.sg1, *sg2 = da + o.sg2, *U = da + o.U, *V = da + o.V,
+                     *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
+        const double* Jinv = mem.p + l.Jinv;
+        double *Jhat = mem.a + l.Jhat, *Upb = mem.a + l.Upb, *Vb = mem.a + l.Vb, *Bb = mem.a + l.Bb, *Gb = mem.a + l.Gb, *sg1b = mem.a + l.sg1b,
+               *sg2b = mem.a + l.sg2b, *Ub = mem.a + l.Ub, *Rb = mem.a + l.Rb, *u2b = mem.a + l.u2b, *u1b = mem.a + l.u1b, *s1b = mem.a + l.s1b,
+               *m1b = mem.a + l.m1b, *gbb = mem.a + l.gbb, *su2 = mem.a + l.su2, *m0b = mem.a + l.m0b, *rbar = mem.a + l.rbar, *xbar = mem.p + l.xbar;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+
+        // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii (k != i),  Jbar = 1/2 J^-T
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int r = e / N, c = e - r * N, i = r / D, k = c / D, bb = c - k * D;
+            Jhat[e] = (i == k) ? 0.0 : 0.5 * (Jinv[c * N + r] - Jinv[(i * D + bb) * N + r]);
+        }
+        b.sync();
+        // (J5) adjoints that are sums over k for fixed i
+        for (int e = b.tid; e < N * P; e += b.nthr) {              // Upbar_i[a][f] = -sum_k sum_b Jhat_ik[a][b] T_ik[f][b]
+            const int r = e / P, f = e - r * P, i = r / D;
+            double acc = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double tv = (f == bb) ? t.tc[bb] : (f == D + bb) ? t.ts[bb] : (f == 2 * D) ? t.td[bb] : 0.0;
+                    acc -= Jhat[r * N + k * D + bb] * tv;
+                }
+            }
+            Upb[e] = acc;
+        }
+        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]
+            const int r = e / HS, g = e - r * HS;
+            double acc = 0;
+            for (int k = 0; k < n; ++k)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[F::iG(k, g, bb)];
+            Bb[e] = acc;
+        }
+        for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
+            const int k = e / (HS * D), r = e - k * HS * D, g = r / D, bb = r - g * D;
+            double acc = 0;
+            for (int i = 0; i < n; ++i)
+#pragma unroll
+                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[F::iB(i, a, g)];
+            Gb[e] = acc;
+        }
+        for (int e = b.tid; e < n * HT; e += b.nthr) {             // Vbar_i[a][h] = -sum_k sum_b Jhat_ik[a][b] sig_t(u_ik[h]) q_ik[h][b]
+            const int i = e / HT, h = e - i * HT;
+            double wt[P]; const double bt = th[F::o_t0b + h];
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
+            double vb[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) vb[a] = 0;
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+                double u = bt + wt[2 * D] * pf.del, q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
+                }
+                const double sg = sigmoid_only(u);
+#pragma unroll
+                for (int a = 0; a < D; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) vb[a] -= Jhat[(i * D + a) * N + k * D + bb] * sg * q[bb];
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) Vb[(i * D + a) * HT + h] = vb[a];
+        }
+        b.sync();
+        // (J4) G adjoint -> sg1bar (first part);  (J3) Up_i = (1/n) (U_i diag sg1_i) W0^T -> Ubar, sg1bar (second part)
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int p = e / HS, h = e - p * HS;
+            double w_c[D], w_s[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
+            const double w_d = th[F::o_W0 + 2 * D * HS + h];
+            double sb = 0;
+            for (int q = 0; q < n; ++q) {
+                if (q == p) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, p, q, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double dG = (Gb[(p * HS + h) * D + bb] - Gb[(q * HS + h) * D + bb]) * rn * rn;
+                    sb += dG * (w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb]);
+                }
+            }
+            double acc = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int f = 0; f < P; ++f) acc += Upb[(p * D + a) * P + f] * U[(p * D + a) * HS + h] * th[F::o_W0 + f * HS + h];
+            sg1b[e] = sb + acc * rn;
+        }
+        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Ubar_i[a][g]
+            const int r = e / HS, g = e - r * HS, i = r / D;
+            double acc = 0;
+#pragma unroll
+            for (int f = 0; f < P; ++f) acc += Upb[r * P + f] * th[F::o_W0 + f * HS + g];
+            Ub[e] = acc * rn * sg1[i * HS + g];
+        }
+        b.sync();
+        // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]
+        for (int e = b.tid; e < N * HS; e += b.nthr) {
+            const int r = e / HS, h = e - r * HS;
+            double acc = 0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) acc += Ub[r * HS + g] * th[F::o_Wa + g * HS + h] + Bb[r * HS + g] * th[F::o_Wb + g * HS + h];
+#pragma unroll
+            for (int g = 0; g < HT; ++g) acc += rn * Vb[r * HT + g] * th[F::o_Wc + g * HS + h];
+            Rb[e] = acc;
+        }
+        b.sync();
+        // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  u2bar = sg2bar sg2'   (zbar = 0: no s2bar)
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double sb = 0;
+#pragma unroll
+            for (int a = 0; a < D; ++a) sb += Rb[(i * D + a) * HS + h] * th[F::o_fw + h * D + a];
+            sg2b[e] = sb;
+            const double g2 = sg2[e];
+            u2b[e] = sb * g2 * (1.0 - g2);
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {                 // sum_i u2bar_i[h]
+            double acc = 0;
+            for (int i = 0; i < n; ++i) acc += u2b[i * HS + h];
+            su2[h] = acc;
+        }
+        b.sync();
+        for (int g = b.tid; g < HS; g += b.nthr) {                 // gbarbar[g] = sum_h Wb[g][h] su2[h]
+            double acc = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wb + g * HS + h] * su2[h];
+            gbb[g] = acc;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * HS; e += b.nthr) {             // s1bar, u1bar
+            const int i = e / HS, g = e - i * HS;
+            double acc = rn * gbb[g];
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wa + g * HS + h] * u2b[i * HS + h];
+            s1b[e] = acc;
+            const double g1 = sg1[e];
+            u1b[e] = acc * g1 + sg1b[e] * g1 * (1.0 - g1);
+        }
+        for (int e = b.tid; e < n * HT; e += b.nthr) {             // m1bar_i[g] = sum_h Wc[g][h] u2bar_i[h]
+            const int i = e / HT, g = e - i * HT;
+            double acc = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_Wc + g * HS + h] * u2b[i * HS + h];
+            m1b[e] = acc;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * P; e += b.nthr) {              // m0bar_i[f] = sum_h W0[f][h] u1bar_i[h]
+            const int i = e / P, f = e - i * P;
+            double acc = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) acc += th[F::o_W0 + f * HS + h] * u1b[i * HS + h];
+            m0b[e] = acc;
+        }
+        b.sync();
+        // pair pass: adjoints of the features t0_ik (value: t0bar) and of their r-derivatives T_ik (Tc, Ts, Td), then rbar_ik
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = e / n, k = e - i * n;
+            if (i == k) {
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) rbar[e * D + bb] = 0.0;
+                continue;
+            }
+            typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+            TCol t; tcols(pf, c1, c2c, t);
+            double Jh[D][D];
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) Jh[a][bb] = Jhat[(i * D + a) * N + k * D + bb];
+            double t0b[P], Tc[D], Ts[D], Td[D];
+#pragma unroll
+            for (int f = 0; f < P; ++f) t0b[f] = rn * m0b[i * P + f];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) {
+                double c = 0, s = 0, d = 0;
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    c -= Jh[a][bb] * Up[(i * D + a) * P + bb];
+                    s -= Jh[a][bb] * Up[(i * D + a) * P + D + bb];
+                    d -= Jh[a][bb] * Up[(i * D + a) * P + 2 * D];
+                }
+                Tc[bb] = c; Ts[bb] = s; Td[bb] = d;
+            }
+            for (int g = 0; g < HS; ++g) {                          // G part: q0bar_ik[g][b] = sg1_i[g] (Gbar_i - Gbar_k)[g][b] / n^2
+                const double s1g = sg1[i * HS + g] * rn * rn;
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double q0b = s1g * (Gb[(i * HS + g) * D + bb] - Gb[(k * HS + g) * D + bb]);
+                    Tc[bb] += th[F::o_W0 + bb * HS + g] * q0b;
+                    Ts[bb] += th[F::o_W0 + (D + bb) * HS + g] * q0b;
+                    Td[bb] += th[F::o_W0 + 2 * D * HS + g] * q0b;
+                }
+            }
+            for (int h = 0; h < HT; ++h) {
+                double wt[P];
+#pragma unroll
+                for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
+                double u = th[F::o_t0b + h] + wt[2 * D] * pf.del, q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
+                }
+                const double sg = sigmoid_only(u), sgp = sg * (1.0 - sg);
+                double sgb = 0, qb[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    double jv = 0;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) jv += Jh[a][bb] * V[F::iV(i, a, h)];
+                    sgb -= jv * q[bb];
+                    qb[bb] = -jv * sg;
+                }
+                const double ub = sgb * sgp + rn * m1b[i * HT + h] * sg;     // adjoint of u_t,ik[h]: Jacobian part + primal part
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    t0b[a] += wt[a] * ub; t0b[D + a] += wt[D + a] * ub;
+                    Tc[a] += wt[a] * qb[a]; Ts[a] += wt[D + a] * qb[a]; Td[a] += wt[2 * D] * qb[a];
+                }
+                t0b[2 * D] += wt[2 * D] * ub;
+            }
+            // r-derivatives: d tc_b / d r_b = -c1^2 c2_b, d ts_b / d r_b = -c1^2 s2_b,
+            //                d td_b' / d r_b = delta_bb' (pi/L)^2 c2_b / del - td_b td_b' / del
+            const double pl2 = 4.0 * c2c * c2c;
+            double tdd = 0;
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) tdd += Td[bb] * t.td[bb];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) {
+                double r = t0b[bb] * t.tc[bb] + t0b[D + bb] * t.ts[bb] + t0b[2 * D] * t.td[bb];
+                r += -c1 * c1 * (Tc[bb] * pf.c2[bb] + Ts[bb] * pf.s2[bb]);
+                r += t.rdel * (Td[bb] * pl2 * pf.c2[bb] - t.td[bb] * tdd);
+                rbar[e * D + bb] = r;
+            }
+        }
+        b.sync();
+        for (int e = b.tid; e < N; e += b.nthr) {                  // r_pq = x_p - x_q
+            const int p = e / D, bb = e - p * D;
+            double acc = 0;
+            for (int q = 0; q < n; ++q) acc += rbar[(p * n + q) * D + bb] - rbar[(q * n + p) * D + bb];
+            xbar[e] = acc;
+        }
+        b.sync();
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // Forward Laplacian of the flow: returns this thread's partial sums of  sum_ia g_ia lap_x z_ia  (complex).
+    // Carries (value, |grad_x|^2, lap_x) through the hidden units (SURVEY App. A.1 for the layers):
+    //   lap sp(u) = sig(u) lap u + sig'(u) |grad u|^2
+    // Pair features depend on r = x_i - x_j only: lap_x f(r) = 2 lap_r f, |grad_x f|^2 = 2 |grad_r f|^2.
+    // ------------------------------------------------------------------------------------------------------
+    template <bool AL>
+    static CG_DEVI void forward_laplacian(const CgBlk& b, const double* __restrict__ th, int n, double L, const Mem<AL>& mem,
+                                          const Lay& l, double& q_re, double& q_im) {
+        const CgFastLds& o = l.o;
+        const double* da = mem.a + l.da;
+        const double *sh = da + o.sh, *ch = da + o.ch, *sg1 = da + o.sg1, *sg2 = da + o.sg2, *G = da + o.G;
+        const double* gz = mem.p + l.gz;
+        double *Lm0 = mem.a + l.Lm0, *gu1 = mem.a + l.gu1, *Ls1 = mem.a + l.Ls1, *Lm1 = mem.a + l.Lm1, *Lgb = mem.a + l.Lgb, *Am = mem.a + l.Am,
+               *Hk = mem.a + l.Hk, *SQ = mem.a + l.SQ, *Er = mem.a + l.Er, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
+
+        // pair pass, item (i,h): lap m1_i[h], lap m0_i[f], |grad u1_i[h]|^2
+        for (int e = b.tid; e < n * HM; e += b.nthr) {
+            const int i = e / HM, h = e - i * HM;
+            const bool do_t = h < HT;
+            double wt[P], bt = 0.0;
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = do_t ? th[F::o_t0w + f * HT + h] : 0.0;
+            if (do_t) bt = th[F::o_t0b + h];
+            double acc = 0.0, raw = 0.0;
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, j, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+                double l0d = 0.0;                                   // lap_r of the norm feature
+#pragma unroll
+                for (int a = 0; a < D; ++a) l0d += pl2 * pf.c2[a] - t.td[a] * t.td[a];
+                l0d *= t.rdel;
+                if (do_t) {
+                    double u = bt + wt[2 * D] * pf.del, lu = wt[2 * D] * l0d, gsq = 0.0;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                        lu -= c1 * c1 * (wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a]);
+                        const double q = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
+                        gsq += q * q;
+                    }
+                    const double sg = sigmoid_only(u);
+                    acc += 2.0 * (sg * lu + sg * (1.0 - sg) * gsq);
+                }
+                if (h < P) {
+                    double fv = l0d;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) { if (h == a) fv = -c1 * c1 * pf.c2[a]; if (h == D + a) fv = -c1 * c1 * pf.s2[a]; }
+                    raw += 2.0 * fv;
+                }
+            }
+            if (do_t) Lm1[i * HT + h] = acc * rn;
+            if (h < P) Lm0[i * P + h] = raw * rn;
+        }
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double w_c[D], w_s[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
+            const double w_d = th[F::o_W0 + 2 * D * HS + h];
+            double ssq = 0.0, sq[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) sq[a] = 0.0;
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
+                    ssq += q0 * q0; sq[bb] += q0;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) ssq += sq[a] * sq[a];
+            gu1[e] = ssq * rn * rn;
+        }
+        // per-particle factors of the dense x-gradient of u2:  A_i = Wa^T diag(sg1_i) W0^T (HS x P),  H_k = Wb^T G_k (HS x D)
+        for (int e = b.tid; e < n * HS * P; e += b.nthr) {
+            const int i = e / (HS * P), r = e - i * HS * P, h = r / P, f = r - h * P;
+            double acc = 0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) acc += th[F::o_Wa + g * HS + h] * sg1[i * HS + g] * th[F::o_W0 + f * HS + g];
+            Am[e] = acc;
+        }
+        for (int e = b.tid; e < n * HS * D; e += b.nthr) {
+            const int k = e / (HS * D), r = e - k * HS * D, h = r / D, bb = r - h * D;
+            double acc = 0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) acc += th[F::o_Wb + g * HS + h] * G[F::iG(k, g, bb)];
+            Hk[e] = acc;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * HS; e += b.nthr) {             // lap s1
+            const int i = e / HS, h = e - i * HS;
+            double lu = 0;
+#pragma unroll
+            for (int f = 0; f < P; ++f) lu += th[F::o_W0 + f * HS + h] * Lm0[i * P + f];
+            const double g1 = sg1[e];
+            Ls1[e] = g1 * lu + g1 * (1.0 - g1) * gu1[e];
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {
+            double a = 0;
+            for (int i = 0; i < n; ++i) a += Ls1[i * HS + h];
+            Lgb[h] = a * rn;
+        }
+        // |grad_x u2_i[h]|^2, one particle i at a time:  E_ik[h][b] = d u2_i[h] / d x_kb  (k != i),  E_ii = -sum_k E_ik
+        //   E_ik = -(1/n) A_i T_ik + H_k - (1/n) Wc^T diag(sig_t(u_ik)) Wt^T T_ik
+        for (int i = 0; i < n; ++i) {
+            for (int e = b.tid; e < n * HT; e += b.nthr) {          // SQ[k][g][b] = sig_t(u_ik[g]) q_ik[g][b]
+                const int k = e / HT, g = e - k * HT;
+                if (k == i) {
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = 0.0;
+                    continue;
+                }
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+                const double wd = th[F::o_t0w + 2 * D * HT + g];
+                double u = th[F::o_t0b + g] + wd * pf.del, q[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double wc = th[F::o_t0w + a * HT + g], ws_ = th[F::o_t0w + (D + a) * HT + g];
+                    u += wc * pf.c2[a] + ws_ * pf.s2[a];
+                    q[a] = wc * t.tc[a] + ws_ * t.ts[a] + wd * t.td[a];
+                }
+                const double sg = sigmoid_only(u);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = sg * q[bb];
+            }
+            b.sync();
+            for (int e = b.tid; e < n * HS; e += b.nthr) {
+                const int k = e / HS, h = e - k * HS;
+                if (k == i) {
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = 0.0;
+                    continue;
+                }
+                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
+                TCol t; tcols(pf, c1, c2c, t);
+                const double* A = Am + ((size_t)i * HS + h) * P;
+                double ev[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) ev[bb] = Hk[e * D + bb] - rn * (A[bb] * t.tc[bb] + A[D + bb] * t.ts[bb] + A[2 * D] * t.td[bb]);
+                for (int g = 0; g < HT; ++g) {
+                    const double wc = rn * th[F::o_Wc + g * HS + h];
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) ev[bb] -= wc * SQ[(k * HT + g) * D + bb];
+                }
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = ev[bb];
+            }
+            b.sync();
+            for (int h = b.tid; h < HS; h += b.nthr) {
+                double ssq = 0.0, sm[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) sm[bb] = 0.0;
+                for (int k = 0; k < n; ++k)
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) { const double v = Er[(k * HS + h) * D + bb]; ssq += v * v; sm[bb] += v; }
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) ssq += sm[bb] * sm[bb];
+                Su2[i * HS + h] = ssq;
+            }
+            // (the next particle's SQ pass is separated from this Er read by its own barrier pair)
+        }
+        b.sync();
+        for (int e = b.tid; e < n * HS; e += b.nthr) {             // lap s2 = lap s1 + sg2 lap u2 + sg2' |grad u2|^2
+            const int i = e / HS, h = e - i * HS;
+            double lu = 0;
+#pragma unroll
+            for (int g = 0; g < HS; ++g) lu += th[F::o_Wa + g * HS + h] * Ls1[i * HS + g] + th[F::o_Wb + g * HS + h] * Lgb[g];
+#pragma unroll
+            for (int g = 0; g < HT; ++g) lu += th[F::o_Wc + g * HS + h] * Lm1[i * HT + g];
+            const double g2 = sg2[e];
+            Ls2[e] = Ls1[e] + g2 * lu + g2 * (1.0 - g2) * Su2[e];
+        }
+        b.sync();
+        q_re = 0; q_im = 0;
+        for (int e = b.tid; e < n * D; e += b.nthr) {              // lap z_ia = sum_h Wf[h][a] lap s2_i[h]
+            const int i = e / D, a = e - i * D;
+            double lz = 0;
+#pragma unroll
+            for (int h = 0; h < HS; ++h) lz += th[F::o_fw + h * D + a] * Ls2[i * HS + h];
+            q_re += gz[2 * e] * lz; q_im += gz[2 * e + 1] * lz;
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------------------
+    // second-order jet pass along dir (probe v, or basis direction `basis`): returns this thread's partial sums
+    //   t2 = tr(J^-1 J''),  t3 = tr((J^-1 J')^2),  and (want_phi2) v^T hess(log phi) v through z', z''.
+    // ------------------------------------------------------------------------------------------------------
+    template <bool AL>
+    static CG_DEVI void jet_part(const CgBlk& b, const double* __restrict__ th, int n, double L, const Mem<AL>& mem, const Lay& l,
+                                 const double* __restrict__ dir, int basis, bool want_phi2, double (&red)[4]) {
+        const int N = n * D;
+        const CgFastLds& oj = l.oj;
+        Jet2* xj = (Jet2*)(mem.b + l.xj); Jet2* ja = (Jet2*)(mem.b + l.ja);
+        const double* x = mem.p + l.x; const double* Jinv = mem.p + l.Jinv; double* M = mem.b + l.M;
+        const double* gz = mem.p + l.gz; const double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; const double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd;
+        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
+        b.sync();
+        F::primal(b, th, (const Jet2*)xj, n, L, ja, oj, nullptr, dir ? -1 : basis / D);
+        F::jacobian(b, th, n, L, ja, oj);
+        const Jet2* zj = ja + oj.z; const Jet2* Jj = ja + oj.J;
+        double p_re = 0, p_im = 0, t2 = 0, t3 = 0;
+        if (want_phi2) {
+            for (int e = b.tid; e < N; e += b.nthr) {
+                p_re += gz[2 * e] * zj[e].dd; p_im += gz[2 * e + 1] * zj[e].dd;
+                const int i = e / D, a = e - i * D;
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double zz = zj[e].d * zj[i * D + bb].d;
+                    p_re += zz * Kd[2 * ((a * D + bb) * n + i)]; p_im += zz * Kd[2 * ((a * D + bb) * n + i) + 1];
+                }
+            }
+            for (int e = b.tid; e < n * n; e += b.nthr) {
+                const int i = e / n, q = e - i * n;
+                CgCplx yiq = {0, 0}, yqi = {0, 0};
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double zi = zj[i * D + a].d, zq = zj[q * D + a].d;
+                    yiq.re += zi * Ta[2 * ((a * n + i) * n + q)]; yiq.im += zi * Ta[2 * ((a * n + i) * n + q) + 1];
+                    yqi.re += zq * Ta[2 * ((a * n + q) * n + i)]; yqi.im += zq * Ta[2 * ((a * n + q) * n + i) + 1];
+                }
+                const CgCplx pr = cmul(yiq, yqi);
+                p_re -= pr.re; p_im -= pr.im;
+            }
+        }
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int al = e / N, ga = e - al * N;
+            t2 += Jinv[al * N + ga] * Jj[ga * N + al].dd;
+            double m = 0;
+            for (int k = 0; k < N; ++k) m += Jinv[al * N + k] * Jj[k * N + ga].d;
+            M[e] = m;
+        }
+        b.sync();
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int al = e / N, ga = e - al * N;
+            t3 += M[al * N + ga] * M[ga * N + al];
+        }
+        red[0] = p_re; red[1] = p_im; red[2] = t2; red[3] = t3;
+    }
+
+    template <bool AL>
+    static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
+                                       const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
+                                       int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
+                                       double* __restrict__ lap /*2*/, double* lds, double* ws, const Lay& l) {
+        const int N = n * D;
+        const Mem<AL> mem(lds, ws, l);
+        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l);
+        const bool exact_phi = mode != 1;
+        double s_re, s_im, q_re = 0, q_im = 0;
+        slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im);      // grad <- J^T g
+        b.sync();                                                        // Jhat overlays J, the adjoints overlay C
+        reverse_x<AL>(b, th, n, L, mem, l);
+        {
+            const double* xbar = mem.p + l.xbar;
+            for (int e = b.tid; e < N; e += b.nthr) grad[2 * e] += xbar[e];   // same thread wrote grad[2 e] above
+        }
+        if (exact_phi) forward_laplacian<AL>(b, th, n, L, mem, l, q_re, q_im);
+        double tot[4] = {s_re + q_re, s_im + q_im, 0.0, 0.0};
+        b.sync();                                    // the jet arena overlays the primal arena
+        if (mode == 0) {
+            for (int dir = 0; dir < N; ++dir) {
+                double r[4];
+                jet_part<AL>(b, th, n, L, mem, l, nullptr, dir, false, r);
+                tot[2] += r[2]; tot[3] += r[3];
+                b.sync();
+            }
+        } else {
+            double r[4];
+            jet_part<AL>(b, th, n, L, mem, l, v, 0, mode == 1, r);
+            tot[0] += r[0]; tot[1] += r[1]; tot[2] += r[2]; tot[3] += r[3];
+        }
+        cg_block_sum_n<4>(b, tot, mem.p + l.red);
+        if (b.tid == 0) { lap[0] = tot[0] + 0.5 * (tot[2] - tot[3]); lap[1] = tot[1]; }
+        b.sync();
+    }
+};

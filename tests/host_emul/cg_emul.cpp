@@ -63,6 +63,35 @@ extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, cons
     return -1;
 }
 
+// ---- second-generation grad / Laplacian (cg_lap.hpp): reverse sweep + forward Laplacian + one jet pass ----
+#include "../../coulombgas_amd/csrc/cg_lap.hpp"
+template <int D, int HS, int HT>
+static void emu_gradlap2_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+                           const double* x, int B, int mode, const double* v, double* grad, double* lap, long lds_budget) {
+    using G = CgLap<D, HS, HT>;
+    const auto lay = G::layout(n, 1, mode, (size_t)lds_budget);
+    std::vector<double> ws(lay.ws_total + 8), lds(lay.lds_total + 8), spk((size_t)M * D);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    const double* th = theta;
+    if (lay.th_lds) { memcpy(lds.data() + lay.th, theta, sizeof(double) * G::NP); th = lds.data() + lay.th; }
+    for (int w = 0; w < B; ++w) {
+        if (lay.all_lds)
+            G::template grad_laplacian<true>(b, th, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
+                                             v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, lds.data(), ws.data(), lay);
+        else
+            G::template grad_laplacian<false>(b, th, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
+                                              v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, lds.data(), ws.data(), lay);
+    }
+}
+extern "C" int emu_grad_laplacian2(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                                   const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap, long lds_budget) {
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_gradlap2_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, mode, v, grad, lap, lds_budget); return 0; }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    return -1;
+}
+
 template <int D, int HS, int HT>
 static void emu_vjp_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
                       const double* x, int B, const double* w_re, const double* w_im, double* g, double* score) {
