@@ -1,23 +1,15 @@
 // cg_derivs.hpp -- derivatives of log Psi for the local energy and the parameter gradient.
 //
-//   grad_laplacian : grad_x log Psi (complex), laplacian_x log Psi (complex)          src/logpsi.py:55-172
 //   param_vjp      : sum_b w_re d/dtheta Re log Psi + w_im d/dtheta Im log Psi         src/VMC.py:69-76 + main.py:278
 //                    and per-sample scores d log Psi / d theta                         src/logpsi.py:183-203
+// (the x-derivatives, grad / Laplacian of log Psi, live in cg_lap.hpp)
 //
-// The reference nests AD transforms (jvp(jacrev(logpsi)) with jacfwd + slogdet inside logpsi).  Here:
-//   * x-derivatives: one second-order jet (cg_jet.hpp) per direction v through the *same* templated flow +
-//     structured-Jacobian code as the sampler gives z' = J v, z'', J', J''.  With closed forms for the plane-wave
-//     determinant:
-//        d/de   log phi        = sum_ia g_ia z'_ia ,                 g_ia = T^a_ii,  T^a = D diag(i k^a) D^-1
-//        d2/de2 log phi        = g.z'' + sum_i sum_ab z'_ia z'_ib K^ab_ii - tr(Y Y),  Y = sum_a diag(z'_a) T^a,
-//                                                                    K^ab = D diag(-k^a k^b) D^-1
-//        d/de   1/2 log|det J| = 1/2 tr(J^-1 J') ,   d2/de2 = 1/2 [ tr(J^-1 J'') - tr((J^-1 J')^2) ]
-//     exact Laplacian = sum over the n*d basis directions; Hutchinson variants use the supplied probe v.
-//   * theta-gradient: hand-written reverse pass of the structured forward code (adjoint of every phase of
-//     CgFast::primal / CgFast::jacobian), seeded with zbar = w_re Re g + w_im Im g and Jbar = w_re/2 J^-T.
+// The reference takes jax.jacrev of log Psi (jacfwd + slogdet inside).  Here: a hand-written reverse pass of the
+// structured forward code (adjoint of every phase of CgFast::primal / CgFast::jacobian), seeded with
+// zbar = w_re Re g + w_im Im g (g_ia = d log phi / d z_ia = T^a_ii, T^a = D diag(i k^a) D^-1) and Jbar = w_re/2 J^-T.
 //
-// One workgroup per walker; intermediates live in a per-workgroup HBM workspace (these kernels run once per
-// optimisation step, not per Metropolis step), LDS is used for the fixed-order reductions only.
+// One workgroup per walker; intermediates live in LDS while they fit, otherwise in a per-workgroup HBM workspace (this
+// kernel runs once per optimisation step, not per Metropolis step).
 #pragma once
 #include "cg_flow_fast.hpp"
 
@@ -46,7 +38,7 @@ struct CgDerivs {
     }
     static size_t adj_doubles(int n) { return adj_layout(n).total; }
     struct Ws {   // offsets in doubles into the per-workgroup workspace
-        size_t da, ja, x, xj, Jc, Jinv, M, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, zs, total;
+        size_t da, x, Jc, Jinv, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, total;
     };
     static Ws ws_layout(int n) {
         const size_t N = (size_t)n * D;
@@ -54,48 +46,29 @@ struct CgDerivs {
         Ws w; size_t t = 0;
         auto take = [&](size_t c) { size_t r = t; t += (c + 1) & ~(size_t)1; return r; };
         w.da = take(o.total);             // double arena (primal + jacobian)
-        w.ja = take(3 * (size_t)o.total); // Jet2 arena
-        w.x = take(N); w.xj = take(3 * N);
-        w.Jc = take(N * N); w.Jinv = take(N * N); w.M = take(N * N);
+        w.x = take(N);
+        w.Jc = take(N * N); w.Jinv = take(N * N);
         w.Dc = take(2 * (size_t)n * n); w.Dinv = take(2 * (size_t)n * n);
         w.Ta = take(2 * (size_t)D * n * n); w.Kd = take(2 * (size_t)D * D * n);
         w.gz = take(2 * N); w.zbar = take(N); w.Jbar = take(N * N);
         w.perm = take(N + 42);
         w.adj = take(adj_doubles(n));
         w.gw = take(NP);
-        w.zs = take(3 * N);               // z jets of a split pass (jet_pass_split)
         w.total = t;
         return w;
     }
-    // oj: layout of the Jet2 arena of the directional passes.  When 3 * oj.total doubles fit the LDS (aliased sampler
-    // layout: the passes need primal + Jacobian lifetimes only) the arena lives there -- the passes are latency-bound on
-    // their ~25 barrier-separated phases and an L2 round trip per access made them ~10x slower than their arithmetic.
     // vjp_fast / vjp_da: LDS scratch of the theta-VJP kernel (doubles; 0 = none) and whether the primal arena lives there.
-    // theta_lds: the grad/Laplacian kernel copies theta behind its jet arena (when that costs no workgroup per CU).
-    struct Layout { Ws w; Adj a; CgFastLds o; CgFastLds oj; int jets_in_lds; int vjp_fast; int vjp_da; int theta_lds; };
-    static constexpr size_t JET_LDS_MAX_BYTES = 150 * 1024;
+    struct Layout { Ws w; Adj a; CgFastLds o; int vjp_fast; int vjp_da; };
     static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
     static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
     static Layout layout(int n, int nthr = 256) {
         Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
-        const CgFastLds al = cg_fast_layout(n, D, HS, HT, true, false);
-        l.jets_in_lds = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total) <= JET_LDS_MAX_BYTES ? 1 : 0;
-        l.oj = l.jets_in_lds ? al : l.o;
-        l.theta_lds = 0;
-        if (l.jets_in_lds) {
-            const size_t now = sizeof(double) * (CG_TAB_DOUBLES + lds_doubles(n, nthr) + 3 * (size_t)al.total), with = now + sizeof(double) * NP;
-            const size_t lds_cu = 160 * 1024;
-            auto wgs = [&](size_t bytes) { const size_t k = lds_cu / bytes; return k > 2 ? (size_t)2 : k; };
-            l.theta_lds = with <= lds_cu && wgs(with) == wgs(now) ? 1 : 0;
-        }
         const size_t base = CG_TAB_DOUBLES + lds_doubles(n, nthr), inv = inv_scratch_doubles(n), NN = (size_t)n * D * n * D;
         l.vjp_fast = 0; l.vjp_da = 0;
         if (sizeof(double) * (base + l.o.total + inv - NN) <= VJP_LDS_MAX_BYTES) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
         else if (sizeof(double) * (base + inv) <= VJP_LDS_MAX_BYTES) l.vjp_fast = (int)inv;
         return l;
     }
-    static CG_HD size_t jet_lds_doubles(const Layout& l) { return l.jets_in_lds ? 3 * (size_t)l.oj.total : 0; }
-    static CG_HD size_t theta_lds_doubles(const Layout& l) { return l.theta_lds ? (size_t)NP : 0; }
     static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)l.vjp_fast; }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }
@@ -174,149 +147,6 @@ struct CgDerivs {
             }
         }
         b.sync();
-    }
-
-    // one directional jet pass: fills the Jet2 arena (z, J as jets) for direction dir (N doubles, global/ws)
-    static CG_DEVI void jet_pass(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                 const CgFastLds& o, Jet2* ja, const double* dir, int basis) {
-        const int N = n * D;
-        Jet2* xj = (Jet2*)(ws + w.xj);
-        const double* x = ws + w.x;
-        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
-        b.sync();
-        CG_STAMP(0)
-        F::primal(b, th, (const Jet2*)xj, n, L, ja, o, nullptr, dir ? -1 : basis / D);   // basis pass: sparse tangent
-        F::jacobian(b, th, n, L, ja, o);
-    }
-
-    // Basis-direction pass of the Hutchinson-split mode: z', z'' from the Jet2 primal, J' from a first-order (Dual)
-    // Jacobian assembly.  The Dual arena reuses the Jet2 arena's memory (2/3 of it): the four persistent primal arrays
-    // the assembly reads (sh, ch, sg1, sg2) are carried over through registers, z jets are saved to zsave first.
-    static CG_DEVI void jet_pass_split(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
-                                       const CgFastLds& o, Jet2* ja, Jet2* zsave, int basis) {
-        const int N = n * D;
-        Jet2* xj = (Jet2*)(ws + w.xj);
-        const double* x = ws + w.x;
-        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], e == basis ? 1.0 : 0.0, 0.0);
-        b.sync();
-        CG_STAMP(0)
-        F::primal(b, th, (const Jet2*)xj, n, L, ja, o, nullptr, basis / D);
-        Dual* da2 = (Dual*)ja;
-        const int cnt[4] = {N, N, n * HS, n * HS};
-        const int off[4] = {o.sh, o.ch, o.sg1, o.sg2};
-        for (int e = b.tid; e < N; e += b.nthr) zsave[e] = ja[o.z + e];
-        // carry sh, ch, sg1, sg2 over in chunks of nthr elements (read all, barrier, write all: the arenas overlap)
-        const int cmax = n * HS > N ? n * HS : N;
-        if (cmax <= b.nthr) {                                    // everything fits one chunk: the four arrays side by side
-            const int e = b.tid;
-            Jet2 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (e < cnt[q]) v[q] = ja[off[q] + e];
-            b.sync();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (e < cnt[q]) da2[off[q] + e] = Dual(v[q].v, v[q].d);
-            b.sync();
-        } else {                                                 // array by array in layout order (a Dual lands below its Jet2)
-            for (int q = 0; q < 4; ++q)
-                for (int e0 = 0; e0 < cnt[q]; e0 += b.nthr) {
-                    const int e = e0 + b.tid;
-                    Jet2 v; if (e < cnt[q]) v = ja[off[q] + e];
-                    b.sync();
-                    if (e < cnt[q]) da2[off[q] + e] = Dual(v.v, v.d);
-                    b.sync();
-                }
-        }
-        F::jacobian(b, th, n, L, da2, o);
-    }
-
-    static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
-                                       const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                                       int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
-                                       double* __restrict__ lap /*2*/, double* ws, double* lds, const Layout& lay) {
-        const int N = n * D;
-        const Ws& w = lay.w;
-        const CgFastLds& o = lay.o;
-        CG_STAMP_START(20)
-        setup(b, th, xg, spk, sidx, n, L, ws, w, o, true, lay.jets_in_lds ? lds + lds_doubles(n, b.nthr) : nullptr,
-              jet_lds_doubles(lay), true);
-        CG_STAMP_END(20)
-        const double* Jinv = ws + w.Jinv; const double* Ta = ws + w.Ta; const double* Kd = ws + w.Kd;
-        const double* gz = ws + w.gz; double* M = ws + w.M;
-        const CgFastLds& oj = lay.oj;
-        Jet2* ja = lay.jets_in_lds ? (Jet2*)(lds + lds_doubles(n, b.nthr)) : (Jet2*)(ws + w.ja);
-        double lap_re = 0.0, lap_im = 0.0;
-        const int ndir = N + (mode == 0 ? 0 : 1);
-        for (int dir = 0; dir < ndir; ++dir) {
-            const bool probe = dir == N;
-            CG_STAMP_START(0)
-            const bool split = !probe && mode == 2;        // only J' is needed: first-order Jacobian jets
-            if (split) jet_pass_split(b, th, n, L, ws, w, oj, ja, (Jet2*)(ws + w.zs), dir);
-            else jet_pass(b, th, n, L, ws, w, oj, ja, probe ? v : nullptr, dir);
-            const Jet2* zj = split ? (const Jet2*)(ws + w.zs) : ja + oj.z;
-            const Jet2* Jj = ja + oj.J; const Dual* Jd = (const Dual*)ja + oj.J;
-            const bool want_phi2 = probe ? (mode == 1) : (mode == 0 || mode == 2);   // second derivative of log phi
-            const bool want_jac2 = probe ? true : (mode == 0);                        // second derivative of 1/2 log|det J|
-            // ---- Slater part
-            double a_re = 0, a_im = 0, p_re = 0, p_im = 0;
-            for (int e = b.tid; e < N; e += b.nthr) {
-                a_re += gz[2 * e] * zj[e].d; a_im += gz[2 * e + 1] * zj[e].d;
-                if (want_phi2) {
-                    p_re += gz[2 * e] * zj[e].dd; p_im += gz[2 * e + 1] * zj[e].dd;
-                    const int i = e / D, a = e - i * D;
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) {
-                        const double zz = zj[e].d * zj[i * D + bb].d;
-                        p_re += zz * Kd[2 * ((a * D + bb) * n + i)]; p_im += zz * Kd[2 * ((a * D + bb) * n + i) + 1];
-                    }
-                }
-            }
-            if (want_phi2) {
-                for (int e = b.tid; e < n * n; e += b.nthr) {
-                    const int i = e / n, l = e - i * n;
-                    CgCplx yil = {0, 0}, yli = {0, 0};
-#pragma unroll
-                    for (int a = 0; a < D; ++a) {
-                        const double zi = zj[i * D + a].d, zl = zj[l * D + a].d;
-                        yil.re += zi * Ta[2 * ((a * n + i) * n + l)]; yil.im += zi * Ta[2 * ((a * n + i) * n + l) + 1];
-                        yli.re += zl * Ta[2 * ((a * n + l) * n + i)]; yli.im += zl * Ta[2 * ((a * n + l) * n + i) + 1];
-                    }
-                    const CgCplx pr = cmul(yil, yli);
-                    p_re -= pr.re; p_im -= pr.im;
-                }
-            }
-            // ---- Jacobian part: tr(J^-1 J'), tr(J^-1 J''), tr((J^-1 J')^2)
-            double t1 = 0, t2 = 0, t3 = 0;
-            for (int e = b.tid; e < N * N; e += b.nthr) {
-                const int al = e / N, ga = e - al * N;
-                const double ji = Jinv[al * N + ga];
-                t1 += ji * (split ? Jd[ga * N + al].d : Jj[ga * N + al].d);
-                if (want_jac2) t2 += ji * Jj[ga * N + al].dd;
-            }
-            if (want_jac2) {
-                for (int e = b.tid; e < N * N; e += b.nthr) {
-                    const int al = e / N, ga = e - al * N;
-                    double m = 0;
-                    for (int k = 0; k < N; ++k) m += Jinv[al * N + k] * Jj[k * N + ga].d;
-                    M[e] = m;
-                }
-                b.sync();
-                for (int e = b.tid; e < N * N; e += b.nthr) {
-                    const int al = e / N, ga = e - al * N;
-                    t3 += M[al * N + ga] * M[ga * N + al];
-                }
-            }
-            {   // the seven sums of this direction in one reduction (2 barriers)
-                double red[7] = {a_re, a_im, t1, p_re, p_im, t2, t3};
-                cg_block_sum_n<7>(b, red, lds);
-                a_re = red[0]; a_im = red[1]; t1 = red[2]; p_re = red[3]; p_im = red[4]; t2 = red[5]; t3 = red[6];
-            }
-            if (want_phi2) { lap_re += p_re; lap_im += p_im; }
-            if (want_jac2) lap_re += 0.5 * (t2 - t3);
-            if (!probe && b.tid == 0) { grad[2 * dir] = a_re + 0.5 * t1; grad[2 * dir + 1] = a_im; }
-            b.sync();
-            CG_STAMP_END(8)
-        }
-        if (b.tid == 0) { lap[0] = lap_re; lap[1] = lap_im; }
     }
 
     // ------------------------------------------------------------------------------------------------------

@@ -6,7 +6,14 @@
 #elif defined(CG_ONLY_3_4_4)
 #define CG_FAST_CONFIGS(X) X(3, 4, 4)
 #else
-#define CG_FAST_CONFIGS(X) X(2, 16, 16) X(3, 16, 16) X(2, 4, 4) X(3, 4, 4) X(2, 8, 8) X(3, 8, 8) X(2, 32, 32)
+// two groups = two translation units per kernel family (compiled in parallel): A is the shape of every shipped run
+#define CG_FAST_CONFIGS_A(X) X(2, 16, 16)
+#define CG_FAST_CONFIGS_B(X) X(3, 16, 16) X(2, 4, 4) X(3, 4, 4) X(2, 8, 8) X(3, 8, 8) X(2, 32, 32)
+#define CG_FAST_CONFIGS(X) CG_FAST_CONFIGS_A(X) CG_FAST_CONFIGS_B(X)
+#endif
+#if !defined(CG_FAST_CONFIGS_A)
+#define CG_FAST_CONFIGS_A(X) CG_FAST_CONFIGS(X)
+#define CG_FAST_CONFIGS_B(X)
 #endif
 
 // Sampler kernels additionally specialised on the particle number and the workgroup size: X(D, HS, HT, N, THREADS).

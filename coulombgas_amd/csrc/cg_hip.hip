@@ -103,7 +103,7 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
     }
     auto fail = [&](const char* what, hipError_t err) {
         g_last_error = std::string("cg_create: ") + what + ": " + hipGetErrorString(err);
-        delete c; return CG_ERR_HIP;
+        cg_destroy(c); return CG_ERR_HIP;          // frees whatever was created so far (every member is null-checked)
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
     hipDeviceProp_t prop;

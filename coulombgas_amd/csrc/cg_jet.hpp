@@ -55,45 +55,8 @@ CG_DEVI double cg_softplus(double u) { return softplus_only(u); }
 CG_DEVI Jet2 cg_softplus(Jet2 u) { Jet2 s, g; cg_softplus_sigmoid(u, s, g); return s; }
 
 
-// ---- first-order dual numbers (value + one directional derivative) -------------------------------------------------
-// Same operator set as Jet2.  Used where only J' is needed (the basis-direction passes of the Hutchinson-split
-// Laplacian: the second-order part of the Jacobian jets would be thrown away), at ~1/3 of the Jet2 arithmetic.
-struct Dual {
-    double v, d;
-    Dual() = default;
-    CG_DEVI Dual(double a) : v(a), d(0.0) {}
-    CG_DEVI Dual(double a, double b) : v(a), d(b) {}
-};
-CG_DEVI Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
-CG_DEVI Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
-CG_DEVI Dual operator-(Dual a) { return {-a.v, -a.d}; }
-CG_DEVI Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
-CG_DEVI Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
-CG_DEVI Dual operator*(Dual b, double a) { return {a * b.v, a * b.d}; }
-CG_DEVI Dual operator+(Dual a, double b) { return {a.v + b, a.d}; }
-CG_DEVI Dual operator+(double b, Dual a) { return {a.v + b, a.d}; }
-CG_DEVI Dual operator-(Dual a, double b) { return {a.v - b, a.d}; }
-CG_DEVI Dual operator-(double b, Dual a) { return {b - a.v, -a.d}; }
-CG_DEVI Dual& operator+=(Dual& a, Dual b) { a.v += b.v; a.d += b.d; return a; }
-CG_DEVI Dual& operator-=(Dual& a, Dual b) { a.v -= b.v; a.d -= b.d; return a; }
-CG_DEVI void cg_sincos(Dual a, Dual& s, Dual& c, bool = false) {
-    double sv, cv; sincos(a.v, &sv, &cv);
-    s = {sv, cv * a.d}; c = {cv, -sv * a.d};
-}
-CG_DEVI Dual cg_sqrt(Dual a) { const double r = sqrt(a.v); return {r, 0.5 * a.d / r}; }
-CG_DEVI Dual cg_rcp(Dual a) { const double r = 1.0 / a.v; return {r, -r * r * a.d}; }
-CG_DEVI void cg_softplus_sigmoid(Dual u, Dual& sp, Dual& sg) {
-    double s, g; softplus_sigmoid(u.v, s, g);
-    sp = {s, g * u.d}; sg = {g, g * (1.0 - g) * u.d};
-}
-CG_DEVI Dual cg_sigmoid(Dual u) { const double g = sigmoid_only(u.v); return {g, g * (1.0 - g) * u.d}; }
-CG_DEVI Dual cg_softplus(Dual u) { Dual s, g; cg_softplus_sigmoid(u, s, g); return s; }
-
-
 // value part / "carries derivatives" trait of the scalar types the flow code is instantiated with
 CG_DEVI double cg_val(double a) { return a; }
 CG_DEVI double cg_val(const Jet2& a) { return a.v; }
-CG_DEVI double cg_val(const Dual& a) { return a.v; }
 template <class T> struct CgIsJet { static constexpr bool value = false; };
 template <> struct CgIsJet<Jet2> { static constexpr bool value = true; };
-template <> struct CgIsJet<Dual> { static constexpr bool value = true; };

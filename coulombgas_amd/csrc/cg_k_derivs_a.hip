@@ -1,63 +1,17 @@
-// cg_k_derivs.hip -- grad / Laplacian of log Psi (cg_lap.hpp), theta-VJP and per-sample scores (cg_derivs.hpp), the score
-// reductions and the quantum Fisher matrix + their entry points.
+// cg_k_derivs_a.hip -- derivative kernels of the (2, 16, 16) flow (every shipped run), the score reductions, the quantum Fisher
+// matrix and the entry points of the family.  The other instantiations are compiled in cg_k_derivs_b.hip.
 #include "cg_host.hpp"
 #include "cg_derivs.hpp"
 #include "cg_lap.hpp"
 
-#ifndef CG_LAP_LDS_BYTES
-#define CG_LAP_LDS_BYTES (80 * 1024)
-#endif
+#define CG_UNIT_CONFIGS(X) CG_FAST_CONFIGS_A(X)
+#define CG_UNIT_NAME(f) cg_derivs_a_##f
+#include "cg_k_derivs.inc"
 
-// grad / Laplacian of log Psi w.r.t. x (cg_lap.hpp): one workgroup per walker, persistent over the batch.
-// AL: every array of the kernel lives in LDS (the BASELINE size n = 13: 78 KB, two workgroups per CU); otherwise the
-// blocks that do not fit the budget use the per-workgroup HBM workspace.  Register budget: 2 waves per SIMD.
-template <int D, int HS, int HT, bool AL>
-__global__ void __launch_bounds__(256, 2) k_grad_lap2(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode,
-                           const double* __restrict__ v, double* __restrict__ grad, double* __restrict__ lap,
-                           double* ws, typename CgLap<D, HS, HT>::Lay lay) {
-    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
-    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
-    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
-    const int n = m.n, N = n * D;
-    const double* th = theta;
-    if (lay.th_lds) {                    // per-lane weight reads from LDS instead of the vector L1
-        double* th_l = lds + lay.th;
-        for (int e = b.tid; e < CgFast<D, HS, HT>::NPARAM; e += b.nthr) th_l[e] = theta[e];
-        th = th_l;
-    }
-    __syncthreads();
-    CG_STAMP_INIT
-    for (int w = blockIdx.x; w < B; w += gridDim.x) {
-        CgLap<D, HS, HT>::template grad_laplacian<AL>(b, th, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
-                                                      v ? v + (size_t)w * N : nullptr, grad + (size_t)w * N * 2, lap + 2 * w,
-                                                      lds, ws + (size_t)blockIdx.x * lay.ws_total, lay);
-        b.sync();
-    }
-    CG_STAMP_FLUSH
-}
-
-template <int D, int HS, int HT>
-__global__ void __launch_bounds__(256, CG_DERIV_WAVES_OF(D)) k_param_vjp(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab, const double* __restrict__ x, const int* __restrict__ sidx, int B,
-                            const double* __restrict__ w_re, const double* __restrict__ w_im,
-                            double* __restrict__ partial /* gridDim.x x P */, double* __restrict__ score /* nullable B x P x 2 */,
-                            double* ws, size_t ws_per_walker, typename CgDerivs<D, HS, HT>::Layout lay) {
-    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
-    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
-    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
-    __syncthreads();
-    const int n = m.n, N = n * D;
-    constexpr int P = CgFast<D, HS, HT>::NPARAM;
-    double* gacc = partial ? partial + (size_t)blockIdx.x * P : nullptr;
-    if (gacc) for (int e = b.tid; e < P; e += b.nthr) gacc[e] = 0.0;
-    b.sync();
-    for (int w = blockIdx.x; w < B; w += gridDim.x) {
-        CgDerivs<D, HS, HT>::param_vjp(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L,
-                                       w_re ? w_re[w] : 1.0, w_im ? w_im[w] : 0.0, gacc,
-                                       score ? score + (size_t)w * P * 2 : nullptr,
-                                       ws + (size_t)blockIdx.x * ws_per_walker, lds, lay);
-        b.sync();
-    }
-}
+int cg_derivs_b_grad_lap(cg_ctx* c, int nt, int grid, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v,
+                         double* grad, double* lap);
+int cg_derivs_b_param_vjp(cg_ctx* c, int nt, int grid, const CgDev& m, const double* x, const int* sidx, int B, const double* w_re,
+                          const double* w_im, double* partial, double* score);
 
 // deterministic second-stage reduction of per-workgroup partial gradients: out[p] = sum_g partial[g][p]
 __global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int P, double* __restrict__ out) {
@@ -168,28 +122,11 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     }
     const CgDev m = make_dev(c);
     bool launched = false;
-    // LDS budget: half a CU (two workgroups of 256 threads per CU = 2 waves per SIMD)
-    const size_t lds_budget = (size_t)CG_LAP_LDS_BYTES / sizeof(double) - CG_TAB_DOUBLES;
-#define CG_X(D, HS, HT)                                                                                              \
-    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                   \
-        const auto dl = CgLap<D, HS, HT>::layout(n, nt, mode, lds_budget);                                          \
-        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)dl.lds_total);                                \
-        if ((rc = ensure_ws(c, sizeof(double) * ((size_t)dl.ws_total * grid + 8)))) return rc;                      \
-        if (dl.all_lds) {                                                                                           \
-            if ((rc = set_lds(c, k_grad_lap2<D, HS, HT, true>, lds))) return rc;                                    \
-            hipLaunchKernelGGL((k_grad_lap2<D, HS, HT, true>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
-                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
-                               (double*)c->ws, dl);                                                                 \
-        } else {                                                                                                    \
-            if ((rc = set_lds(c, k_grad_lap2<D, HS, HT, false>, lds))) return rc;                                   \
-            hipLaunchKernelGGL((k_grad_lap2<D, HS, HT, false>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
-                               (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev, (double*)al.dev, \
-                               (double*)c->ws, dl);                                                                 \
-        }                                                                                                           \
-        launched = true;                                                                                            \
-    }
-    CG_FAST_CONFIGS(CG_X)
-#undef CG_X
+    if ((rc = cg_derivs_a_grad_lap(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev,
+                                   (double*)al.dev)) < 0) return rc;
+    if (rc == 0 && (rc = cg_derivs_b_grad_lap(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev,
+                                              (double*)ag.dev, (double*)al.dev)) < 0) return rc;
+    launched = rc == 1;
     if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_grad_laplacian: configuration not instantiated");
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
@@ -251,20 +188,13 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
                                        partial, (double*)asc.dev))) return rc;
         launched = true;
     }
-#define CG_X(D, HS, HT)                                                                                               \
-    if (!launched && c->dim == D && c->hs == HS && c->ht == HT) {                                                    \
-        const size_t wsw = CgDerivs<D, HS, HT>::ws_doubles(n);                                                       \
-        const auto dl = CgDerivs<D, HS, HT>::layout(n, nt);                                                          \
-        const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + CgDerivs<D, HS, HT>::lds_doubles(n, nt) + CgDerivs<D, HS, HT>::vjp_lds_doubles(dl)); \
-        if ((rc = ensure_ws(c, sizeof(double) * wsw * grid))) return rc;                                             \
-        if ((rc = set_lds(c, k_param_vjp<D, HS, HT>, lds))) return rc;                                               \
-        hipLaunchKernelGGL((k_param_vjp<D, HS, HT>), dim3(grid), dim3(nt), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk, (const double*)c->d_tab, (const double*)ax.dev, \
-                           (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev, partial,           \
-                           (double*)asc.dev, (double*)c->ws, wsw, dl);                                               \
-        launched = true;                                                                                             \
+    if (!launched) {
+        if ((rc = cg_derivs_a_param_vjp(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev,
+                                        partial, (double*)asc.dev)) < 0) return rc;
+        if (rc == 0 && (rc = cg_derivs_b_param_vjp(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev,
+                                                   (const double*)awi.dev, partial, (double*)asc.dev)) < 0) return rc;
+        launched = rc == 1;
     }
-    CG_FAST_CONFIGS(CG_X)
-#undef CG_X
     if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
     if (g_theta)
         hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);

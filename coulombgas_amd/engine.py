@@ -273,6 +273,7 @@ class Engine:
         if self._mode == _lib.CG_PTR_HOST and self._scores_ready(xb, s):
             check(lib().cg_scores_fisher(self._ctx, _p(F), _p(sm)), self._ctx)
         else:
+            self._score_key = None      # cg_quantum_fisher overwrites the resident scores: the cached key no longer describes them
             check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
         return F, sm[:, 0] + 1j * sm[:, 1]
 

@@ -33,6 +33,7 @@ class EmulEngine:
         self.P = sum(int(np.prod(s)) for _, _, s in ravel_order(2, spsize, tpsize, dim))
         self.theta = None
         self.ew = None
+        self.lds_budget = 10080        # doubles; which blocks of cg_lap.hpp's layout count as LDS-resident
 
     def set_params(self, theta):
         self.theta = np.ascontiguousarray(theta, dtype=np.float64).ravel().copy()
@@ -108,7 +109,7 @@ class EmulEngine:
         if v is not None:
             v = np.ascontiguousarray(v, dtype=np.float64).reshape(B, self.n, self.dim)
         g = np.empty((B, self.n, self.dim, 2)); l = np.empty((B, 2))
-        assert lib().emu_grad_laplacian(*self._args(), _p(s), _p(xb), B, int(mode), _p(v), _p(g), _p(l)) == 0
+        assert lib().emu_grad_laplacian(*self._args(), _p(s), _p(xb), B, int(mode), _p(v), _p(g), _p(l), C.c_long(self.lds_budget)) == 0
         return (g[..., 0] + 1j * g[..., 1]).reshape(lead + (self.n, self.dim)), (l[:, 0] + 1j * l[:, 1]).reshape(lead)
 
     def param_vjp(self, x, sidx, w_re, w_im):

@@ -43,30 +43,11 @@ extern "C" int emu_logpsi(int n, int dim, int hs, int ht, double L, const double
 // ---- derivative kernels (cg_derivs.hpp) on the host shim ----
 #include "../../coulombgas_amd/csrc/cg_derivs.hpp"
 
-template <int D, int HS, int HT>
-static void emu_gradlap_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
-                          const double* x, int B, int mode, const double* v, double* grad, double* lap) {
-    using G = CgDerivs<D, HS, HT>;
-    const auto lay = G::layout(n, 1);              // Jet arena in "LDS" (aliased layout) whenever the GPU kernel would
-    std::vector<double> ws(G::ws_doubles(n) + 8), lds(G::lds_doubles(n, 1) + G::jet_lds_doubles(lay) + 8), spk((size_t)M * D);
-    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
-    CgBlk b{0, 1};
-    for (int w = 0; w < B; ++w)
-        G::grad_laplacian(b, theta, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, mode,
-                          v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, ws.data(), lds.data(), lay);
-}
-extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
-                                  const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap) {
-#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_gradlap_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, mode, v, grad, lap); return 0; }
-    CG_FAST_CONFIGS(CG_X)
-#undef CG_X
-    return -1;
-}
-
-// ---- second-generation grad / Laplacian (cg_lap.hpp): reverse sweep + forward Laplacian + one jet pass ----
+// ---- grad / Laplacian (cg_lap.hpp): reverse sweep + forward Laplacian + jet pass(es); lds_budget (doubles) selects
+// which blocks of the kernel's memory would live in LDS on the GPU (here it only changes the layout) ----
 #include "../../coulombgas_amd/csrc/cg_lap.hpp"
 template <int D, int HS, int HT>
-static void emu_gradlap2_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+static void emu_gradlap_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
                            const double* x, int B, int mode, const double* v, double* grad, double* lap, long lds_budget) {
     using G = CgLap<D, HS, HT>;
     const auto lay = G::layout(n, 1, mode, (size_t)lds_budget);
@@ -84,9 +65,9 @@ static void emu_gradlap2_t(int n, double L, const double* theta, const double* s
                                               v ? v + (size_t)w * n * D : nullptr, grad + (size_t)w * n * D * 2, lap + 2 * w, lds.data(), ws.data(), lay);
     }
 }
-extern "C" int emu_grad_laplacian2(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+extern "C" int emu_grad_laplacian(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
                                    const int* sidx, const double* x, int B, int mode, const double* v, double* grad, double* lap, long lds_budget) {
-#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_gradlap2_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, mode, v, grad, lap, lds_budget); return 0; }
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { emu_gradlap_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, mode, v, grad, lap, lds_budget); return 0; }
     CG_FAST_CONFIGS(CG_X)
 #undef CG_X
     return -1;

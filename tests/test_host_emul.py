@@ -125,3 +125,17 @@ def test_general_depth_param_vjp_vs_oracle(n, dim, depth, hs, ht, L):
     emul_lib().emu_gen_param_vjp(n, dim, depth, hs, ht, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, None, None, None, p(sc))
     qr = R.make_quantum_score(lpt)(R.T(x), R.T(theta), sb).numpy()
     assert np.abs(sc[..., 0] + 1j * sc[..., 1] - qr).max() < 1e-10 * max(1.0, np.abs(qr).max())
+
+
+@pytest.mark.parametrize("budget", [0, 3000, 6000, 1 << 20])
+def test_grad_laplacian_memory_placements(budget):
+    """cg_lap.hpp places its three memory blocks in LDS or in the HBM workspace depending on the LDS budget; every
+    placement must give the same numbers (n = 13: all three modes against the golden vectors)."""
+    g = np.load(GOLDEN + "/golden_n13_d2.npz")
+    eng = EmulEngine(int(g["n"]), int(g["dim"]), 2, int(g["spsize"]), int(g["tpsize"]), float(g["L"]), g["sp_indices"])
+    eng.lds_budget = budget
+    eng.set_params(g["theta"])
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    for mode, gk, lk in ((0, "grad", "lap_exact"), (1, "grad_hutch", "lap_hutch"), (2, "grad_split", "lap_split")):
+        gr, lp = eng.grad_laplacian(g["x"], g["state_idx"], mode, g["v"])
+        assert rel(gr, g[gk]) < 1e-11 and rel(lp, g[lk]) < 1e-10
