@@ -23,32 +23,23 @@ HBM_PEAK_GBS = 8000.0                                               # MI355X_MIC
 
 
 def synthetic(n, dim, B, Emax, rank):
-    """SURVEY 8(d) synthetic inputs."""
-    from tests.common import orbitals, box_length, state_indices
-    L = box_length(n, dim)
-    sp = orbitals(dim, Emax)
-    rng_p = np.random.default_rng(np.random.PCG64(1))
-    from coulombgas_amd.flow import ravel_order
-    theta = np.concatenate([(np.zeros(int(np.prod(s))) if leaf == "b" else 0.01 * rng_p.standard_normal(int(np.prod(s))))
-                            for _, leaf, s in ravel_order(2, 16, 16, dim)])
-    rng = np.random.default_rng(np.random.PCG64(1000 + rank))
-    sidx = state_indices(np.random.default_rng(np.random.PCG64(rank)), B, n, sp.shape[0])
-    x = rng.uniform(0.0, L, (B, n, dim))
-    return L, sp, theta, sidx, x
+    """SURVEY 8(d) synthetic inputs (coulombgas_amd/synthetic.py)."""
+    from coulombgas_amd.synthetic import bench_inputs
+    return bench_inputs(n, dim, B, Emax, rank)
 
 
-def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=12.0):
-    """Times the CPU restatement (oracle/cg_oracle.c: the algorithm the reference executes -- dense forward-mode
-    Jacobian with n*d tangents, two LU log-dets) on a bounded sample of the same workload, all host cores."""
+DENSE_AD_FLOPS_PER_WALKER_STEP = {13: 2.7e6, 29: 24e6, 57: 170e6}   # SURVEY 8(d): what XLA / the C port execute (dense jacfwd)
+
+
+def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=15.0, reps=5):
+    """Times the CPU restatement (oracle/cg_oracle.c: the algorithm the reference executes -- dense forward-mode Jacobian with
+    n*d tangents, SIMD over the tangents, two LU log-dets; OpenMP over walkers) on the host cores: BASELINE.md section 3 --
+    config 1's shape (B = 128, the full call) and a bounded sample of the timed workload's shape, each the MEDIAN of `reps`
+    repetitions after one warm-up.  `value` is the larger-batch rate (the shape of the metric)."""
     import ctypes as C
     from coulombgas_amd.build import build_oracle
-    try:
-        path = build_oracle()
-        if path is None:
-            return None
-        lib = C.CDLL(path)
-    except Exception as e:       # no compiler on the box and no prebuilt library
-        return {"value": None, "unit": "walker-steps/s", "error": str(e)}
+    path = build_oracle()
+    lib = C.CDLL(path)
     lib.cgo_mcmc.restype = C.c_double
     lib.cgo_num_threads.restype = C.c_int
     p = lambda a: a.ctypes.data_as(C.c_void_p)
@@ -63,39 +54,67 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=12.0)
         lib.cgo_mcmc(C.c_int(n), C.c_int(dim), C.c_int(2), C.c_int(16), C.c_int(16), C.c_double(L), p(theta), p(sp), C.c_int(sp.shape[0]),
                      p(ss), p(xs), C.c_int(Bs), C.c_int(steps), C.c_double(stddev), p(noise), p(unif), p(logp))
         return time.perf_counter() - t0
-    Bs, steps = min(64 * cores, x.shape[0]), 5
-    t = run(Bs, steps)                                   # calibration (also warm-up)
-    rate = Bs * steps / t
-    Bs2 = int(min(x.shape[0], max(Bs, rate * budget_s / mc_steps // cores * cores)))
-    t2 = run(Bs2, mc_steps)
-    return {"value": Bs2 * mc_steps / t2, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
-            "sample": "%d walkers x %d mc_steps of the same workload (n=%d), %.1f s, OpenMP over walkers" % (Bs2, mc_steps, n, t2)}
+
+    def median_rate(Bs, steps):
+        run(Bs, steps)                                   # warm-up
+        ts = sorted(run(Bs, steps) for _ in range(reps))
+        return Bs * steps / ts[len(ts) // 2], ts
+
+    t = run(min(2 * cores, x.shape[0]), 2)               # calibration
+    rate = min(2 * cores, x.shape[0]) * 2 / t
+    per_run = budget_s / (2 * (reps + 1))
+    # config 1's shape: B = 128 (the whole call if it fits the budget, otherwise fewer Metropolis steps of it)
+    B1 = min(128, x.shape[0]); s1 = int(max(1, min(mc_steps, rate * per_run / B1)))
+    r1, t1 = median_rate(B1, s1)
+    # the timed workload's shape: as many of its walkers as the budget allows (a multiple of the core count), all mc_steps
+    B2 = int(min(x.shape[0], max(cores, rate * per_run / mc_steps // cores * cores))); s2 = mc_steps
+    r2, t2 = median_rate(B2, s2)
+    fl = DENSE_AD_FLOPS_PER_WALKER_STEP.get(n)
+    return {"value": r2, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
+            "sample": "median of %d runs: %d walkers x %d mc_steps of the timed workload (n=%d), %.2f s per run" % (reps, B2, s2, n, t2[len(t2) // 2]),
+            "config1_shape": {"value": r1, "sample": "median of %d runs: B=%d x %d mc_steps, %.2f s per run" % (reps, B1, s1, t1[len(t1) // 2])},
+            "gflops_per_core": (r2 * fl / cores / 1e9) if fl else None,
+            "gflops_note": "dense forward-mode count of SURVEY 8(d) (%.3g flop per walker-step at n=%d), the arithmetic this port executes" % (fl or 0, n),
+            "runs_s": [round(v, 4) for v in t2]}
 
 
-def energy_check(eng, n, dim, L, sp, theta, sidx, x, rs=10.0, kappa=10, Gmax=15, sample=2):
-    """BASELINE.json's second half of the metric: relative error of <E_loc> (src/VMC.py:38-41, exact Laplacian) of the
-    HIP path vs the CPU restatement (oracle/cg_ref.py, torch.func) on identical inputs: a bounded sample of the walkers
-    the timed chains ended on.  The oracle is used here as the checker only."""
+def energy_check(eng, n, dim, L, sp, theta, sidx, x, rs=10.0, kappa=10, Gmax=15, n_split=64, n_exact=16):
+    """BASELINE.json's second half of the metric: relative error of <E_loc> (src/VMC.py:38-41) of the HIP path vs the CPU
+    restatement (oracle/cg_ref.py, torch.func) on identical inputs: walkers the timed chains ended on, in the
+    Hutchinson-split mode of BASELINE config 3 (fixed probe, n_split walkers) and with the exact Laplacian (n_exact walkers).
+    The oracle is used here as the checker only."""
     import torch
     import coulombgas_amd as cg
     from oracle import cg_ref as R
     t0 = time.perf_counter()
-    xs = np.ascontiguousarray(x[:sample]); ss = np.ascontiguousarray(sidx[:sample])
     G = cg.kpoints(dim, Gmax)
     Vconst = n * rs / L * cg.Madelung(dim, kappa, G)
     eng.set_ewald(kappa, G, rs)
-    g, lap = eng.grad_laplacian(xs, ss, 0, None)
-    E = -lap - (g ** 2).sum(axis=(-2, -1)) + eng.ewald(xs) + Vconst
     rflow = R.FermiNet(2, 16, 16, L)
     rparams = R.flow_unravel(R.T(theta), 2, 16, 16, dim)
-    _, rfn = R.make_logpsi_grad_laplacian(R.make_logpsi(rflow, sp, L))
-    gr, lr = rfn(R.T(xs), rparams, torch.as_tensor(ss.astype(np.int64)), None)
-    Er = (-lr - (gr ** 2).sum(dim=(-2, -1))).numpy() + R.potential_energy(R.T(xs), kappa, G, L, rs).numpy() + Vconst
-    return {"E_mean_gpu": float(E.real.mean()), "E_mean_cpu": float(Er.real.mean()),
-            "rel_err_mean": float(abs(E.real.mean() - Er.real.mean()) / abs(Er.real.mean())),
-            "rel_err_max_per_walker": float(np.abs(E - Er).max() / np.abs(Er).max()),
-            "walkers": int(sample), "seconds": time.perf_counter() - t0,
-            "what": "E_loc = -lap - sum grad^2 + Ewald + Vconst, exact Laplacian, rs=%.1f kappa=%d Gmax=%d; HIP path vs oracle/cg_ref.py" % (rs, kappa, Gmax)}
+    r_logpsi = R.make_logpsi(rflow, sp, L)
+    r_logphi, r_logjacdet = R.make_logphi_logjacdet(rflow, sp, L)
+    out = {"what": "E_loc = -lap - sum grad^2 + Ewald + Vconst, rs=%.1f kappa=%d Gmax=%d; HIP path vs oracle/cg_ref.py" % (rs, kappa, Gmax)}
+    v = np.random.default_rng(99).standard_normal(x.shape)
+    for name, cnt, mode in (("hutchinson_split", n_split, 2), ("exact", n_exact, 0)):
+        if cnt <= 0:
+            continue
+        xs = np.ascontiguousarray(x[:cnt]); ss = np.ascontiguousarray(sidx[:cnt]); vs = np.ascontiguousarray(v[:cnt])
+        g, lap = eng.grad_laplacian(xs, ss, mode, vs if mode else None)
+        E = -lap - (g ** 2).sum(axis=(-2, -1)) + eng.ewald(xs) + Vconst
+        if mode:
+            _, rfn = R.make_logpsi_grad_laplacian(r_logpsi, hutchinson=True, logphi=r_logphi, logjacdet=r_logjacdet)
+            gr, lr = rfn(R.T(xs), rparams, torch.as_tensor(ss.astype(np.int64)), R.T(vs))
+        else:
+            _, rfn = R.make_logpsi_grad_laplacian(r_logpsi)
+            gr, lr = rfn(R.T(xs), rparams, torch.as_tensor(ss.astype(np.int64)), None)
+        Er = (-lr - (gr ** 2).sum(dim=(-2, -1))).numpy() + R.potential_energy(R.T(xs), kappa, G, L, rs).numpy() + Vconst
+        out[name] = {"walkers": int(cnt), "E_mean_gpu": float(E.real.mean()), "E_mean_cpu": float(Er.real.mean()),
+                     "rel_err_mean": float(abs(E.real.mean() - Er.real.mean()) / abs(Er.real.mean())),
+                     "rel_err_max_per_walker": float(np.abs(E - Er).max() / np.abs(Er).max())}
+    out["rel_err_mean"] = max(out[k]["rel_err_mean"] for k in ("hutchinson_split", "exact") if k in out)
+    out["seconds"] = time.perf_counter() - t0
+    return out
 
 
 def main():
@@ -110,6 +129,7 @@ def main():
     ap.add_argument("--Emax", type=int, default=25)
     ap.add_argument("--threads", type=int, default=0, help="threads per walker workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-energy-check", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,12 +157,9 @@ def main():
         eng.set_block_threads(args.threads)
     comm_kind = "none"
     if world > 1 or force_dist:
-        try:
-            comm = RcclComm(eng, rank, world); comm_kind = "rccl via cg_allreduce_mean"
-        except Exception as e:      # keep the scaling run alive: same library (RCCL) through torch.distributed
-            print("bench.py: RcclComm failed (%s); using torch.distributed nccl all_reduce" % e, file=sys.stderr)
-            from coulombgas_amd.comm import TorchDistComm
-            comm = TorchDistComm(device="cuda"); comm_kind = "rccl via torch.distributed"
+        # the library's own RCCL path (cg_comm_* / cg_allreduce_mean) or nothing: a broken communicator must fail the run,
+        # not hand the scaling curve to torch.distributed
+        comm = RcclComm(eng, rank, world); comm_kind = "rccl via cg_allreduce_mean"
     else:
         comm = NullComm()
 
@@ -222,10 +239,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             _, _, _, sidx0, x0 = synthetic(n, dim, B, args.Emax, 0)
             cpu = cpu_baseline(n, dim, L, sp, theta, sidx0, x0, args.mc_steps, args.mc_stddev)
-            try:
-                energy = energy_check(eng, n, dim, L, sp, theta, sidx, x_final, sample=2 if n <= 16 else 1)
-            except Exception as e:             # the checker must never take the timing line down
-                energy = {"error": repr(e)}
+            if not args.no_energy_check:
+                big = n > 16                   # the torch oracle is minutes per walker beyond n = 13: fewer walkers there
+                energy = energy_check(eng, n, dim, L, sp, theta, sidx, x_final, n_split=4 if big else 64, n_exact=0 if big else 16)
         out = {"metric": "walker-steps/sec (batch x mcsteps/s), n=%d 2D batch %d" % (n, B), "value": value,
                "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

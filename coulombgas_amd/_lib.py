@@ -63,6 +63,14 @@ PROTOTYPES = {
     "cg_scores_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "cg_scores_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_scores_fisher": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_scores_mean": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "cg_local_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_abs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cg_clip_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    "cg_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_uint64]),
+    "cg_axpby": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_size_t]),
+    "cg_scale_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_double]),
     "cg_fisher_real": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cg_cholesky": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "cg_spd_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -86,7 +86,7 @@ def build_oracle(force=False):
         return None
     os.makedirs(outdir, exist_ok=True)
     if force or _newer(out, [src]):
-        _run(["gcc", "-O3", "-march=x86-64-v3", "-fopenmp", "-shared", "-fPIC", "-o", out, src, "-lm"])
+        _run(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", "-o", out, src, "-lm"])
     return out
 
 

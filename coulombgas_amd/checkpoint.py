@@ -18,9 +18,16 @@ def ckpt_filename(epoch, path):
 
 
 class _Stub:
-    """Placeholder for jax / optax / haiku objects that carry no data this path needs (optimizer state tuples, ...)."""
+    """Placeholder for jax / optax / haiku objects (optimizer state tuples, ...).  Records its constructor arguments in
+    __new__ as well: namedtuples are unpickled with NEWOBJ, which never calls __init__ -- the mu / nu / count of an optax
+    Adam state would otherwise be dropped."""
+    def __new__(cls, *a, **k):
+        o = object.__new__(cls)
+        o.args, o.kwargs = a, k
+        return o
+
     def __init__(self, *a, **k):
-        self.args, self.kwargs = a, k
+        pass
 
     def __setstate__(self, state):
         self.state = state
@@ -62,6 +69,23 @@ def load_data(filename):
 def save_data(data, filename):
     with open(filename, "wb") as f:
         pickle.dump(data, f)
+
+
+def adam_state_from_ckpt(opt_state):
+    """Adam moments of a checkpoint as this package's adam() state {"count", "mu", "nu"}: passes such a dict through, and
+    converts an optax state pickled by the reference (a tuple holding ScaleByAdamState(count, mu, nu), loaded as _Stub)."""
+    if isinstance(opt_state, dict) and {"count", "mu", "nu"} <= set(opt_state):
+        return opt_state
+    stack = [opt_state]
+    while stack:
+        o = stack.pop()
+        if isinstance(o, _Stub):
+            if len(o.args) == 3:
+                return {"count": int(np.asarray(o.args[0])), "mu": _to_numpy(o.args[1]), "nu": _to_numpy(o.args[2])}
+            stack.extend(o.args)
+        elif isinstance(o, (list, tuple)):
+            stack.extend(o)
+    return None
 
 
 def load_log(filename):

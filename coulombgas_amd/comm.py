@@ -18,6 +18,10 @@ class NullComm:
     def pmean(self, a):
         return a
 
+    def pmean_d(self, a, count=None, index=0):
+        """in-place mean over the ranks of a device-resident array (or of `count` elements from `index`): nothing to do"""
+        return a
+
     def close(self):
         pass
 
@@ -40,6 +44,13 @@ class TorchDistComm:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         out = (t / self.world).numpy()
         return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
+
+    def pmean_d(self, a, count=None, index=0):
+        """array handles of the CPU test engine are numpy arrays: all-reduce in place"""
+        flat = a.reshape(-1)
+        n = flat.size - index if count is None else count
+        flat[index:index + n] = self.pmean(flat[index:index + n])
+        return a
 
     def close(self):
         pass
@@ -81,9 +92,14 @@ class RcclComm:
         out = flat.reshape(arr.shape)
         return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
 
-    def pmean_dev(self, buf, count):
+    def pmean_d(self, a, count=None, index=0):
+        """in-place RCCL all-reduce (mean) of a DeviceArray, or of `count` doubles from element `index` of its buffer, on the
+        engine's stream: no host staging (main.py:280, src/VMC.py:46-53, src/sr.py:73-82)"""
         from ._lib import lib, check
-        check(lib().cg_allreduce_mean(self._h, buf.ptr, int(count)), self.engine._ctx)
+        n = (a.size * (2 if a.complex_pairs else 1) - index) if count is None else count
+        check(lib().cg_allreduce_mean(self._h, a.ptr_at(index), int(n)), self.engine._ctx)
+        a.version += 1
+        return a
 
     def close(self):
         if self._h is not None:
@@ -102,6 +118,17 @@ def _torch_broadcast_bytes(payload):
         t = t.cuda()
     dist.broadcast(t, src=0)
     return bytes(t.cpu().tolist())
+
+
+def allgather(comm, a):
+    """(world, ...) array of every rank's `a` (same shape on all ranks), through the mean all-reduce the communicators
+    provide: rank r contributes world * a in slot r.  Used off the hot path only (checkpoints, main.py:374-381)."""
+    a = np.asarray(a, dtype=np.float64)
+    if comm.world == 1:
+        return a[None]
+    buf = np.zeros((comm.world,) + a.shape)
+    buf[comm.rank] = a * comm.world
+    return np.asarray(comm.pmean(buf)).reshape(buf.shape)
 
 
 _COMM = NullComm()

@@ -2,6 +2,7 @@
 // solver of libcoulombgas_hip.so (C-ABI: include/coulombgas.h).  The walker kernels live in cg_k_*.hip.
 #include "cg_host.hpp"
 #include "cg_ewald.hpp"
+#include "cg_rng.hpp"
 
 thread_local std::string g_last_error;
 
@@ -31,6 +32,95 @@ __global__ void k_wrap(double* __restrict__ x, size_t count, double L) {
 __global__ void k_scale(double* __restrict__ buf, size_t count, double s) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) buf[i] *= s;
+}
+
+// ---- optimisation-step kernels that keep the per-walker energies on the device --------------------------------------
+// K8: local energies and their moments, src/VMC.py:39-58 before the pmean.
+//   kinetic = -lap - sum_ia grad_ia^2 (complex square, :39);  E_loc = kinetic + V + Vconst (:40-41);
+//   F_loc = logp_states / beta + Re E_loc (:42);  sums of K, K^2, V, V^2, E, E^2, F, F^2, -logp, logp^2 (:44-53).
+// 16 lanes (one DPP row) per walker: the lanes stride over the n*d complex gradient entries (coalesced), the row is
+// reduced by xor-shuffles, lane 0 of the row assembles the energies; the ten sums of a block's 16 walkers go through
+// one wave-butterfly + LDS reduction; one row of partial sums per block, summed in fixed order by k_rows_sum.
+__global__ void __launch_bounds__(256) k_local_energy(const double* __restrict__ grad, const double* __restrict__ lap,
+                                                      const double* __restrict__ V, const double* __restrict__ logp_states,
+                                                      int B, int N, double Vconst, double rbeta, double* __restrict__ eloc,
+                                                      double* __restrict__ floc, double* __restrict__ partial) {
+    __shared__ double scratch[10 * 4];
+    const int sub = threadIdx.x & 15, w = blockIdx.x * 16 + (threadIdx.x >> 4);
+    double sr = 0.0, si = 0.0;
+    if (w < B) {
+        const double* g = grad + (size_t)w * N * 2;
+        for (int e = sub; e < N; e += 16) { const double a = g[2 * e], b = g[2 * e + 1]; sr += a * a - b * b; si += 2.0 * a * b; }
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) { sr += __shfl_xor(sr, off); si += __shfl_xor(si, off); }
+    double v[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v[k] = 0.0;
+    if (w < B && sub == 0) {
+        const double kr = -lap[2 * w] - sr, ki = -lap[2 * w + 1] - si;
+        const double pot = V[w] + Vconst;
+        const double er = kr + pot;
+        const double lps = logp_states ? logp_states[w] : 0.0;
+        const double fl = lps * rbeta + er;
+        eloc[2 * w] = er; eloc[2 * w + 1] = ki;
+        if (floc) floc[w] = fl;
+        v[0] = kr; v[1] = kr * kr; v[2] = pot; v[3] = pot * pot; v[4] = er; v[5] = er * er; v[6] = fl; v[7] = fl * fl;
+        v[8] = -lps; v[9] = lps * lps;
+    }
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    cg_block_sum_n<10>(b, v, scratch);
+    if (threadIdx.x < 10) partial[(size_t)blockIdx.x * 10 + threadIdx.x] = v[threadIdx.x];
+}
+// mean absolute deviation, local part: sum_b |e_b - c|  (src/VMC.py:63 real F_loc, :72 complex E_loc; c = the pmean'd mean,
+// read from device memory so that no host round trip sits between the all-reduce and this kernel)
+__global__ void __launch_bounds__(256) k_abs_dev(const double* __restrict__ e, int B, int cplx, const double* __restrict__ center,
+                                                 double* __restrict__ partial) {
+    __shared__ double scratch[4];
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const double c = center[0];
+    double v[1] = {0.0};
+    if (w < B) {
+        if (cplx) { const double dr = e[2 * w] - c, di = e[2 * w + 1]; v[0] = sqrt(dr * dr + di * di); }
+        else v[0] = fabs(e[w] - c);
+    }
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    cg_block_sum_n<1>(b, v, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = v[0];
+}
+// out[p] = scale * sum_r partial[r][p], rows summed in fixed order (deterministic)
+__global__ void k_rows_sum(const double* __restrict__ partial, int rows, int P, double scale, double* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += partial[(size_t)r * P + p];
+    out[p] = a * scale;
+}
+// Weights of the theta-VJP behind jax.jacrev(quantum_lossfn) (src/VMC.py:72-76, main.py:278):
+//   E_c = clip(E_loc, <E> - 5 tv, <E> + 5 tv) with the lexicographic complex order of the JAX generation the reference
+//   targets;  d/dtheta 2 mean Re(logPsi conj(E_c)) = sum_b (2/B) [Re E_c,b dRe logPsi_b + Im E_c,b dIm logPsi_b].
+// cplx = 0: real clip of F_loc (src/VMC.py:64), w_re = scale * F_c, w_im untouched.
+__global__ void __launch_bounds__(256) k_clip_weights(const double* __restrict__ e, int B, int cplx, const double* __restrict__ center,
+                                                      const double* __restrict__ tv, double scale, double* __restrict__ w_re,
+                                                      double* __restrict__ w_im) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= B) return;
+    const double lo = center[0] - 5.0 * tv[0], hi = center[0] + 5.0 * tv[0];
+    if (!cplx) { const double f = e[w]; w_re[w] = scale * fmin(fmax(f, lo), hi); return; }
+    double re = e[2 * w], im = e[2 * w + 1];
+    if (re < lo || (re == lo && im < 0.0)) { re = lo; im = 0.0; }          // maximum(a, lo)
+    if (hi < re || (hi == re && 0.0 < im)) { re = hi; im = 0.0; }          // minimum(., hi)
+    w_re[w] = scale * re; w_im[w] = scale * im;
+}
+// standard normals from the Philox stream (seed, offset + i): the Hutchinson probe jax.random.normal(key, x.shape) of
+// src/logpsi.py:110 drawn on the device (bit-parity with jax.random is not a goal; parity runs pass v in)
+__global__ void __launch_bounds__(256) k_randn(double* __restrict__ out, size_t count, uint64_t seed, uint64_t offset) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) out[i] = cg_philox_normal(seed, offset + i, 0x5eedu, 0u);
+}
+__global__ void __launch_bounds__(256) k_axpby(double a, const double* __restrict__ x, double bcoef, double* __restrict__ y, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) y[i] = a * x[i] + (bcoef != 0.0 ? bcoef * y[i] : 0.0);
 }
 
 // fp64 peak micro-benchmarks (roofline denominators for bench.py; /opt/skills/guides has no f64 row)
@@ -341,6 +431,98 @@ int cg_debug_stamps(cg_ctx* c, unsigned long long* out64, int clear) {
     return CG_OK;
 }
 #endif
+
+/* ---- device-resident optimisation step (src/VMC.py:39-76, main.py:277-289) ---- */
+int cg_local_energy(cg_ctx* c, const double* grad, const double* lap, const double* V, const double* logp_states, int B,
+                    double Vconst, double beta, double* eloc, double* floc, double* moments) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (B == 0) return CG_OK;
+    if (!grad || !lap || !V || !eloc || !moments || !(beta > 0)) CG_FAIL(c, CG_ERR_ARG, "cg_local_energy: NULL argument or beta <= 0");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_local_energy: arena");
+    const int N = c->n * c->dim;
+    Arg ag{(void*)grad, nullptr, sizeof(double) * (size_t)B * N * 2, true, false};
+    Arg al{(void*)lap, nullptr, sizeof(double) * (size_t)B * 2, true, false};
+    Arg av{(void*)V, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg as{(void*)logp_states, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ae{eloc, nullptr, sizeof(double) * (size_t)B * 2, false, true};
+    Arg af{floc, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg am{moments, nullptr, sizeof(double) * 10, false, true};
+    Arg* all[] = {&ag, &al, &av, &as, &ae, &af, &am};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int grid = (B + 15) / 16;
+    double* partial = (double*)arena_take(c, sizeof(double) * (size_t)grid * 10);
+    if (!partial) CG_FAIL(c, CG_ERR_HIP, "cg_local_energy: workspace allocation failed");
+    hipLaunchKernelGGL(k_local_energy, dim3(grid), dim3(256), 0, c->stream, (const double*)ag.dev, (const double*)al.dev, (const double*)av.dev,
+                       (const double*)as.dev, B, N, Vconst, 1.0 / beta, (double*)ae.dev, (double*)af.dev, partial);
+    hipLaunchKernelGGL(k_rows_sum, dim3(1), dim3(64), 0, c->stream, (const double*)partial, grid, 10, 1.0 / (double)B, (double*)am.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_abs_dev(cg_ctx* c, const double* e, int B, int is_complex, const double* center, double* out) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (B == 0) return CG_OK;
+    if (!e || !center || !out) CG_FAIL(c, CG_ERR_ARG, "cg_abs_dev: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_abs_dev: arena");
+    Arg ae{(void*)e, nullptr, sizeof(double) * (size_t)B * (is_complex ? 2 : 1), true, false};
+    Arg ac{(void*)center, nullptr, sizeof(double), true, false};
+    Arg ao{out, nullptr, sizeof(double), false, true};
+    Arg* all[] = {&ae, &ac, &ao};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    const int grid = (B + 255) / 256;
+    double* partial = (double*)arena_take(c, sizeof(double) * (size_t)grid);
+    if (!partial) CG_FAIL(c, CG_ERR_HIP, "cg_abs_dev: workspace allocation failed");
+    hipLaunchKernelGGL(k_abs_dev, dim3(grid), dim3(256), 0, c->stream, (const double*)ae.dev, B, is_complex ? 1 : 0, (const double*)ac.dev, partial);
+    hipLaunchKernelGGL(k_rows_sum, dim3(1), dim3(64), 0, c->stream, (const double*)partial, grid, 1, 1.0 / (double)B, (double*)ao.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_clip_weights(cg_ctx* c, const double* e, int B, int is_complex, const double* center, const double* tv, double scale,
+                    double* w_re, double* w_im) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (B == 0) return CG_OK;
+    if (!e || !center || !tv || !w_re || (is_complex && !w_im)) CG_FAIL(c, CG_ERR_ARG, "cg_clip_weights: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_clip_weights: arena");
+    Arg ae{(void*)e, nullptr, sizeof(double) * (size_t)B * (is_complex ? 2 : 1), true, false};
+    Arg ac{(void*)center, nullptr, sizeof(double), true, false};
+    Arg at{(void*)tv, nullptr, sizeof(double), true, false};
+    Arg awr{w_re, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg awi{is_complex ? w_im : nullptr, nullptr, sizeof(double) * (size_t)B, false, true};
+    Arg* all[] = {&ae, &ac, &at, &awr, &awi};
+    for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
+    hipLaunchKernelGGL(k_clip_weights, dim3((B + 255) / 256), dim3(256), 0, c->stream, (const double*)ae.dev, B, is_complex ? 1 : 0,
+                       (const double*)ac.dev, (const double*)at.dev, scale, (double*)awr.dev, (double*)awi.dev);
+    for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
+    return finish(c);
+}
+int cg_randn(cg_ctx* c, double* out, size_t count, uint64_t seed, uint64_t offset) {
+    if (!c) return CG_ERR_ARG;
+    if (count == 0) return CG_OK;
+    if (!out) CG_FAIL(c, CG_ERR_ARG, "cg_randn: out is NULL");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_randn: arena");
+    Arg ao{out, nullptr, sizeof(double) * count, false, true};
+    if ((rc = stage(c, ao))) return rc;
+    hipLaunchKernelGGL(k_randn, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, (double*)ao.dev, count, seed, offset);
+    if ((rc = unstage(c, ao))) return rc;
+    return finish(c);
+}
+/* y = a x + b y on DEVICE pointers (both pointer modes): the accumulators of main.py:281-289 kept in HBM */
+int cg_axpby(cg_ctx* c, double a, const double* x_dev, double b, double* y_dev, size_t count) {
+    if (!c) return CG_ERR_ARG;
+    if (count == 0) return CG_OK;
+    if (!x_dev || !y_dev) CG_FAIL(c, CG_ERR_ARG, "cg_axpby: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, a, x_dev, b, y_dev, count);
+    CG_HIP(c, hipGetLastError());
+    return CG_OK;
+}
 
 int cg_scale_dev(cg_ctx* c, double* buf, size_t count, double s) {
     if (!c) return CG_ERR_ARG;

@@ -206,4 +206,3 @@ int cg_gen_run_mcmc(cg_ctx* c, double* x, const int* sidx, int B, int steps, dou
 int cg_gen_run_param_vjp(cg_ctx* c, int grid, const double* x, const int* sidx, int B, const double* w_re, const double* w_im,
                          double* partial, double* score);
 int cg_gen_run_grad_lap(cg_ctx* c, int grid, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap);
-extern "C" int cg_scale_dev(cg_ctx* c, double* buf, size_t count, double s);

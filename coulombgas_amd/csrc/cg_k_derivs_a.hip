@@ -255,6 +255,19 @@ int cg_scores_fisher(cg_ctx* c, double* fisher, double* score_mean) {
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
 }
+int cg_scores_mean(cg_ctx* c, double* score_mean) {
+    if (!c) return CG_ERR_ARG;
+    if (!c->d_scores || c->scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_scores_mean: cg_scores_compute has not been called");
+    if (!score_mean) CG_FAIL(c, CG_ERR_ARG, "cg_scores_mean: NULL output");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->scores_B, P = c->P;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_scores_mean: arena");
+    Arg asm_{score_mean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
+    if ((rc = stage(c, asm_))) return rc;
+    if ((rc = score_reduce(c, (const double*)c->d_scores, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
+    if ((rc = unstage(c, asm_))) return rc;
+    return finish(c);
+}
 int cg_quantum_fisher(cg_ctx* c, const double* x, const int32_t* sidx, int B, double* fisher, double* score_mean) {
     if (c && (!fisher || !score_mean)) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: NULL output");
     if (c && B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_quantum_fisher: empty batch");

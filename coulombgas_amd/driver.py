@@ -8,9 +8,11 @@ The variational density matrix is passed as `sampler`, `log_prob` (+ `log_prob_v
 jax.jacrev(classical_lossfn) needs, and `classical_score_fn` if params_van is to be trained).  With
 coulombgas_amd.make_autoregressive_sampler (the reference's Transformer, host numpy) all four come from one object.
 `GroundStateSampler` is the trivial stand-in (zero temperature: every walker in the n lowest orbitals, log_prob = 0)."""
+import os
 import numpy as np
 from . import sr as _sr
-from .comm import get_comm
+from .comm import get_comm, allgather
+from .checkpoint import ckpt_filename, load_data, save_data, adam_state_from_ckpt
 from .vmc import sample_stateindices_and_x, make_loss
 from .logpsi import make_logpsi, make_logphi_logjacdet, make_logp, make_logpsi_grad_laplacian, make_quantum_score
 from .potential import kpoints, Madelung
@@ -68,32 +70,56 @@ def _tree(f, *trees):
     return f(*trees)
 
 
+def _is_device(a):
+    return not isinstance(a, np.ndarray) and hasattr(a, "ptr")
+
+
 def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, log_prob_vjp=None, comm=None):
     """main.py:263-310.  Returns update(params_van, params_flow, opt_state, state_indices, x, key, acc, final_step) ->
-    (params_van, params_flow, opt_state, acc) with acc the dict of accumulators the reference threads through pmap."""
+    (params_van, params_flow, opt_state, acc) with acc the dict of accumulators the reference threads through pmap.
+    Fisher matrices that arrive as DeviceArrays are accumulated in HBM (Engine.axpby_d), never on the host."""
     def new_acc():
         return {"data": {k: 0.0 for k in DATA_KEYS}, "grads": None, "scores": None, "fishers": None}
+
+    def acc_fisher(acc_f, f):
+        """classical_fisher_acc += ..., quantum_fisher_acc += ..., quantum_score_mean_acc += ... (main.py:285-289); the first
+        step COPIES (the engine's output buffers are overwritten by the next accumulation step)."""
+        out = []
+        for k, b in enumerate(f):
+            a = None if acc_f is None else acc_f[k]
+            if b is None:
+                out.append(None)
+            elif _is_device(b):
+                if a is None:
+                    a = b.eng.scratch("fisher_acc_%d" % k, b.shape)
+                    b.eng.axpby_d(1.0, b, 0.0, a)
+                else:
+                    b.eng.axpby_d(1.0, b, 1.0, a)
+                out.append(a)
+            else:
+                out.append(np.array(b, copy=True) if a is None else a + b)
+        return tuple(out)
 
     def update(params_van, params_flow, opt_state, state_indices, x, key, acc, final_step):
         cm = comm or get_comm()
         acc = acc or new_acc()
         data, classical_lossfn, quantum_lossfn = observable_and_lossfn(params_van, params_flow, state_indices, x, key)
-        grad_flow, score_flow = quantum_lossfn.grad(params_flow)                       # :278
+        grad_flow, score_flow = quantum_lossfn.grad(params_flow, reduce=True)          # :278 + the pmean of :280 on the device
         grad_van = score_van = None
         if log_prob_vjp is not None and params_van is not None:                        # :277
             classical_lossfn(params_van)
             grad_van = log_prob_vjp(params_van, state_indices, classical_lossfn.weights)
             score_van = log_prob_vjp(params_van, state_indices, classical_lossfn.score_weights)
-        flat, unravel = _sr.ravel_pytree({"g": (grad_flow if grad_van is None else {"v": grad_van, "f": grad_flow}),
-                                          "s": (score_flow if score_van is None else {"v": score_van, "f": score_flow})})
-        tree = unravel(cm.pmean(flat))                                                 # :280, one packed all-reduce
-        grads, scores = tree["g"], tree["s"]
+            flat, unravel = _sr.ravel_pytree({"g": grad_van, "s": score_van})
+            tree = unravel(cm.pmean(flat))                                             # :280 (classical part, host model)
+            grad_van, score_van = tree["g"], tree["s"]
+        grads = grad_flow if grad_van is None else {"v": grad_van, "f": grad_flow}
+        scores = score_flow if score_van is None else {"v": score_van, "f": score_flow}
         acc["data"] = {k: acc["data"][k] + data[k] for k in DATA_KEYS}                 # :281-283
         acc["grads"] = grads if acc["grads"] is None else _tree(lambda a, b: a + b, acc["grads"], grads)
         acc["scores"] = scores if acc["scores"] is None else _tree(lambda a, b: a + b, acc["scores"], scores)
         if fishers_fn is not None:                                                     # :285-289
-            f = fishers_fn(params_van, params_flow, state_indices, x)
-            acc["fishers"] = f if acc["fishers"] is None else tuple(None if a is None else a + b for a, b in zip(acc["fishers"], f))
+            acc["fishers"] = acc_fisher(acc["fishers"], fishers_fn(params_van, params_flow, state_indices, x))
         if final_step:                                                                 # :291-307
             d = {k: v / acc_steps for k, v in acc["data"].items()}
             g = _tree(lambda a: a / acc_steps, acc["grads"]); s = _tree(lambda a: a / acc_steps, acc["scores"])
@@ -102,7 +128,10 @@ def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, lo
             else:
                 g_van = _tree(lambda a, b: a - d["F_mean"] * b, g["v"], s["v"])
                 g_flow = _tree(lambda a, b: a - d["E_mean"] * b, g["f"], s["f"])
-            fish = None if acc["fishers"] is None else tuple(None if a is None else a / acc_steps for a in acc["fishers"])
+            fish = None
+            if acc["fishers"] is not None:
+                fish = tuple(None if a is None else (a.eng.scale_d(a, 1.0 / acc_steps) if _is_device(a) else a / acc_steps)
+                             for a in acc["fishers"])
             updates, opt_state = optimizer.update((g_van, g_flow), opt_state, params=fish)
             if updates[0] is not None:
                 params_van = _sr.apply_updates(params_van, updates[0])
@@ -127,9 +156,13 @@ def format_row(i, data, rs, batch_total, acc_steps, accept_rate):
 
 def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sampler, log_prob, params_van=None,
           optimizer=None, sr=None, kappa=10, Gmax=15, mc_therm=10, mc_steps=50, mc_stddev=0.1, acc_steps=1,
-          hutchinson=True, seed=42, log=None, log_prob_vjp=None, classical_score_fn=None, comm=None):
+          hutchinson=True, seed=42, log=None, log_prob_vjp=None, classical_score_fn=None, comm=None, device_resident=True,
+          ckpt_path=None, ckpt_every=100, epoch_finished=0):
     """main.py:216-384 on one rank.  sr = (damping, max_norm) selects hybrid_fisher_sr (main.py:179-184), otherwise
-    `optimizer` (default adam(1e-3)).  Returns (params_van, params_flow, rows) with rows the data.txt lines."""
+    `optimizer` (default adam(1e-3)).  Returns (params_van, params_flow, rows) with rows the data.txt lines.
+    ckpt_path / ckpt_every / epoch_finished: the checkpoints of main.py:374-381 ({"keys", "x", "params_van", "params_flow",
+    "opt_state"}, x with the reference's leading device axis) and the resume of main.py:217-223 (a shipped epoch_*.pkl
+    resumes too).  device_resident: walkers, local energies, scores and Fisher matrices stay in HBM for the whole run."""
     cm = comm or get_comm()
     if log_prob_vjp is None and hasattr(log_prob, "vjp"):          # make_autoregressive_sampler's log_prob carries its own
         log_prob_vjp = log_prob.vjp                                 # reverse pass: the density matrix is trained as well
@@ -147,16 +180,37 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
         optimizer = adam(1e-3)
     opt_state = optimizer.init((params_van, params_flow))
     ss = np.random.SeedSequence(seed).spawn(cm.world)[cm.rank]                        # :237, one key per device
-    rng = np.random.default_rng(ss)
-    x = rng.uniform(0.0, L, (batch, n, dim))                                           # :236
-    key = ss
-    for _ in range(mc_therm):                                                          # :241-246
-        key, _, x, _ = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc_steps, mc_stddev, L, comm=cm)
+    eng = flow.engine(n, dim, sp_indices)
+    first_epoch = 1
+    load_name = ckpt_filename(epoch_finished, ckpt_path) if ckpt_path is not None else None
+    if load_name is not None and epoch_finished > 0 and os.path.isfile(load_name):     # :217-223 resume
+        ck = load_data(load_name)
+        xs = np.asarray(ck["x"], dtype=np.float64)
+        x = xs[cm.rank] if xs.ndim == 4 else xs                                        # leading device axis of the reference
+        params_van, params_flow = ck["params_van"], ck["params_flow"]
+        st = adam_state_from_ckpt(ck.get("opt_state"))
+        if st is not None and isinstance(opt_state, dict):
+            opt_state = st
+        ks = np.asarray(ck["keys"])
+        key = np.random.SeedSequence([int(v) for v in np.atleast_2d(ks)[cm.rank % np.atleast_2d(ks).shape[0]].ravel()])
+        first_epoch = epoch_finished + 1
+        thermalise = False
+    else:
+        rng = np.random.default_rng(ss)
+        x = rng.uniform(0.0, L, (batch, n, dim))                                       # :236
+        key = ss
+        thermalise = True
+    from .engine import Engine, DeviceArray
+    if device_resident and isinstance(eng, Engine):
+        x = DeviceArray.from_numpy(eng, x)            # the walkers live in HBM from here on (main.py:239: replicate / shard)
+    if thermalise:
+        for _ in range(mc_therm):                                                      # :241-246
+            key, _, x, _ = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc_steps, mc_stddev, L, comm=cm)
     logpsi, lgl = make_logpsi_grad_laplacian(logpsi_novmap, hutchinson=hutchinson, logphi=logphi, logjacdet=logjacdet)   # :254-256
     observable_and_lossfn = make_loss(log_prob, logpsi, lgl, kappa, G, L, rs, Vconst, beta, comm=cm)               # :258-259
     update = make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn, log_prob_vjp, comm=cm)
     rows = []
-    for i in range(1, epochs + 1):                                                     # :316-372
+    for i in range(first_epoch, epochs + 1):                                           # :316-372
         acc, accept_acc = update.new_acc(), 0.0
         for a in range(acc_steps):
             key, state_indices, x, accept_rate = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow,
@@ -168,4 +222,11 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
         rows.append(row)
         if log is not None and cm.rank == 0:
             log(row)
+        if ckpt_path is not None and i % ckpt_every == 0:                              # :374-381
+            xs = allgather(cm, np.asarray(x))                                          # (world, batch, n, dim) like the reference
+            ks = allgather(cm, key.generate_state(2, dtype=np.uint32).astype(np.float64)).astype(np.uint32)
+            if cm.rank == 0:
+                os.makedirs(ckpt_path, exist_ok=True)
+                save_data({"keys": ks, "x": xs, "params_van": params_van, "params_flow": params_flow, "opt_state": opt_state},
+                          ckpt_filename(i, ckpt_path))
     return params_van, params_flow, rows

@@ -49,6 +49,83 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class DeviceArray:
+    """An array that lives in HBM -- what a jax device array is to the reference's closures.  The closures of this package
+    accept either numpy arrays (staged through the device per call) or DeviceArrays (no copies: walkers, local energies,
+    scores and Fisher matrices then stay on the GPU for the whole optimisation step).  `np.asarray(a)` downloads.
+    complex_pairs: the buffer holds (..., 2) real pairs that read back as complex128 (the C-ABI's complex layout)."""
+
+    def __init__(self, eng, shape, dtype=np.float64, complex_pairs=False):
+        self.eng, self.shape, self.dtype = eng, tuple(int(v) for v in shape), np.dtype(dtype)
+        self.complex_pairs = bool(complex_pairs)
+        self.buf = DeviceBuffer(eng, self.shape + ((2,) if complex_pairs else ()), self.dtype)
+        self.version = 0          # bumped by every call that writes the buffer (cache keys)
+        self.base, self.index = self, 0
+
+    ndim = property(lambda self: len(self.shape))
+    size = property(lambda self: int(np.prod(self.shape, dtype=np.int64)))
+    ptr = property(lambda self: self.buf.ptr)
+
+    def ptr_at(self, index):
+        """device pointer to element `index` of the underlying real buffer"""
+        return C.c_void_p(self.buf.ptr.value + int(index) * self.dtype.itemsize)
+
+    @staticmethod
+    def from_numpy(eng, a, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = DeviceArray(eng, a.shape, dtype)
+        d.buf.upload(a)
+        return d
+
+    def upload(self, a):
+        self.buf.upload(np.ascontiguousarray(a, dtype=self.dtype).reshape(self.buf.shape))
+        self.version += 1
+        return self
+
+    def numpy(self, start=0, count=None):
+        """download; start / count (elements of the real buffer) select a flat slice"""
+        if start == 0 and count is None:
+            a = self.buf.download()
+            return (a[..., 0] + 1j * a[..., 1]) if self.complex_pairs else a
+        out = np.empty(int(count), dtype=self.dtype)
+        check(lib().cg_memcpy_d2h(self.eng._ctx, _p(out), self.ptr_at(start), out.nbytes), self.eng._ctx)
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def free(self):
+        self.buf.free()
+
+
+class DeviceView:
+    """(P, Q) window into a DeviceArray's buffer (no copy): e.g. the Fisher matrix inside the packed [F | mean score] buffer
+    of hybrid_fisher_sr.  Behaves like a DeviceArray for the accumulators (axpby_d / scale_d) and the solver."""
+
+    def __init__(self, base, index, shape):
+        self.base, self.index, self.shape = base, int(index), tuple(int(v) for v in shape)
+        self.eng, self.dtype, self.complex_pairs = base.eng, base.dtype, False
+
+    size = property(lambda self: int(np.prod(self.shape, dtype=np.int64)))
+    ptr = property(lambda self: self.base.ptr_at(self.index))
+    version = property(lambda self: self.base.version, lambda self, v: setattr(self.base, "version", v))
+
+    def ptr_at(self, i):
+        return self.base.ptr_at(self.index + int(i))
+
+    def numpy(self):
+        return self.base.numpy(self.index, self.size).reshape(self.shape)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+
+def is_device(a):
+    return isinstance(a, DeviceArray)
+
+
 class Engine:
     def __init__(self, n, dim, depth, spsize, tpsize, L, sp_indices=None, device=0):
         self.n, self.dim, self.depth, self.spsize, self.tpsize, self.L = int(n), int(dim), int(depth), int(spsize), int(tpsize), float(L)
@@ -306,6 +383,189 @@ class Engine:
             cre, cim = _f64(center.real), _f64(center.imag)
         check(lib().cg_spd_solve(self._ctx, _p(A), b.size, float(damping), _p(cre), _p(cim), _p(b), _p(x)), self._ctx)
         return x
+
+    # -- device-resident API: DeviceArray in / out, no host copies, asynchronous -----------
+    # These are what make_loss / make_update / hybrid_fisher_sr run on: walkers, gradients, local energies, weights, scores
+    # and Fisher matrices stay in HBM between the sampling call and the parameter update (src/VMC.py:33-76, main.py:270-307).
+    def _dev_call(self, fn, *args):
+        """one C-ABI call in device-pointer mode (restores the mode the engine was in)"""
+        prev = self._mode
+        if prev != _lib.CG_PTR_DEVICE:
+            check(lib().cg_set_pointer_mode(self._ctx, _lib.CG_PTR_DEVICE), self._ctx)
+        try:
+            check(fn(self._ctx, *args), self._ctx)
+        finally:
+            if prev != _lib.CG_PTR_DEVICE:
+                check(lib().cg_set_pointer_mode(self._ctx, prev), self._ctx)
+
+    def scratch(self, tag, shape, dtype=np.float64, complex_pairs=False):
+        """persistent named DeviceArray of this engine (re-allocated only when the shape changes)"""
+        pool = self.__dict__.setdefault("_scratch", {})
+        a = pool.get(tag)
+        shape = tuple(int(v) for v in shape)
+        if a is None or a.shape != shape or a.dtype != np.dtype(dtype) or a.complex_pairs != bool(complex_pairs):
+            if a is not None:
+                a.free()
+            a = pool[tag] = DeviceArray(self, shape, dtype, complex_pairs)
+        return a
+
+    def asdevice(self, a, tag, dtype=np.float64):
+        """DeviceArray as is; a numpy array is uploaded into the scratch array `tag` -- skipped when the same values are
+        already there (state indices of a zero-temperature sampler, an unchanged walker batch)."""
+        if isinstance(a, DeviceArray):
+            return a
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = self.scratch(tag, a.shape, dtype)
+        cache = self.__dict__.setdefault("_upload_cache", {})
+        old = cache.get(tag)
+        if old is None or old[0] is not d or old[2] != d.version or old[1].shape != a.shape or not np.array_equal(old[1], a):
+            d.upload(a)
+            cache[tag] = (d, a.copy(), d.version)
+        return d
+
+    def to_host(self, a):
+        return np.asarray(a)
+
+    def view(self, base, index, shape):
+        return DeviceView(base, index, shape)
+
+    def to_host_slice(self, a, start, count):
+        return a.numpy(start, count)
+
+    def mcmc_d(self, x_d, sidx_d, mc_steps, mc_stddev, seed=0, walker_offset=0, noise=None, unif=None):
+        """the chain of src/MCMC.py:22-39 in place on x_d; returns the number of accepted moves (8-byte read-back)"""
+        B = x_d.shape[0]
+        nz = un = None
+        if noise is not None:
+            nz = self.asdevice(_f64(noise).reshape(mc_steps, B, self.n, self.dim), "mc_noise")
+            un = self.asdevice(_f64(unif).reshape(mc_steps, B), "mc_unif")
+        self._dev_call(lib().cg_mcmc, x_d.ptr, sidx_d.ptr, int(B), int(mc_steps), float(mc_stddev), int(seed), int(walker_offset),
+                       nz.ptr if nz is not None else None, un.ptr if un is not None else None, None, None)
+        x_d.version += 1
+        return self.mcmc_accepts()
+
+    def wrap_d(self, x_d):
+        self._dev_call(lib().cg_wrap, x_d.ptr, int(x_d.shape[0]))
+        x_d.version += 1
+        return x_d
+
+    def randn_d(self, tag, shape, seed, offset=0):
+        out = self.scratch(tag, shape)
+        self._dev_call(lib().cg_randn, out.ptr, out.size, int(seed) & (2 ** 64 - 1), int(offset))
+        out.version += 1
+        return out
+
+    def logpsi_d(self, x_d, sidx_d):
+        out = self.scratch("logpsi", (x_d.shape[0],), complex_pairs=True)
+        self._dev_call(lib().cg_logpsi, x_d.ptr, sidx_d.ptr, int(x_d.shape[0]), out.ptr)
+        out.version += 1
+        return out
+
+    def grad_laplacian_d(self, x_d, sidx_d, mode, v_d=None):
+        B = x_d.shape[0]
+        g = self.scratch("grad", (B, self.n, self.dim), complex_pairs=True)
+        l = self.scratch("lap", (B,), complex_pairs=True)
+        self._dev_call(lib().cg_grad_laplacian, x_d.ptr, sidx_d.ptr, int(B), int(mode), v_d.ptr if v_d is not None else None, g.ptr, l.ptr)
+        g.version += 1; l.version += 1
+        return g, l
+
+    def ewald_d(self, x_d):
+        V = self.scratch("V", (x_d.shape[0],))
+        self._dev_call(lib().cg_ewald, x_d.ptr, int(x_d.shape[0]), V.ptr)
+        V.version += 1
+        return V
+
+    def local_energy_d(self, grad_d, lap_d, V_d, logp_states_d, Vconst, beta):
+        """K8: (E_loc (B) complex, F_loc (B), moments (10)) of src/VMC.py:39-58 before the pmean"""
+        B = V_d.shape[0]
+        eloc = self.scratch("eloc", (B,), complex_pairs=True)
+        floc = self.scratch("floc", (B,))
+        mom = self.scratch("moments", (10,))
+        self._dev_call(lib().cg_local_energy, grad_d.ptr, lap_d.ptr, V_d.ptr, logp_states_d.ptr if logp_states_d is not None else None,
+                       int(B), float(Vconst), float(beta), eloc.ptr, floc.ptr, mom.ptr)
+        for a in (eloc, floc, mom):
+            a.version += 1
+        return eloc, floc, mom
+
+    def abs_dev_d(self, e_d, center, tag="tv"):
+        """mean_b |e_b - center| with center = (DeviceArray, index) read on the device (src/VMC.py:63,72 before the pmean)"""
+        out = self.scratch(tag, (1,))
+        self._dev_call(lib().cg_abs_dev, e_d.ptr, int(e_d.shape[0]), 1 if e_d.complex_pairs else 0, center[0].ptr_at(center[1]), out.ptr)
+        out.version += 1
+        return out
+
+    def clip_weights_d(self, e_d, center, tv_d, scale, tag="w"):
+        B = e_d.shape[0]
+        w_re = self.scratch(tag + "_re", (B,))
+        w_im = self.scratch(tag + "_im", (B,)) if e_d.complex_pairs else None
+        self._dev_call(lib().cg_clip_weights, e_d.ptr, int(B), 1 if e_d.complex_pairs else 0, center[0].ptr_at(center[1]), tv_d.ptr,
+                       float(scale), w_re.ptr, w_im.ptr if w_im is not None else None)
+        w_re.version += 1
+        if w_im is not None:
+            w_im.version += 1
+        return w_re, w_im
+
+    def scores_compute_d(self, x_d, sidx_d):
+        """per-sample scores S = d log Psi / d theta resident on the device (src/logpsi.py:183-203); recomputed only when the
+        walkers, the state indices or theta changed"""
+        key = (id(x_d), x_d.version, id(sidx_d), sidx_d.version, id(self._theta))
+        if getattr(self, "_score_key_d", None) != key:
+            self._dev_call(lib().cg_scores_compute, x_d.ptr, sidx_d.ptr, int(x_d.shape[0]))
+            self._score_key_d = key
+            self._score_key = None          # the host-mode cache describes other walkers now
+
+    def scores_vjp_d(self, w_re_d, w_im_d, out, out_index=0):
+        self._dev_call(lib().cg_scores_vjp, w_re_d.ptr, w_im_d.ptr, out.ptr_at(out_index))
+        out.version += 1
+
+    def scores_mean_d(self, out, out_index=0):
+        self._dev_call(lib().cg_scores_mean, out.ptr_at(out_index))
+        out.version += 1
+
+    def scores_fisher_d(self, out, fisher_index, mean_index):
+        self._dev_call(lib().cg_scores_fisher, out.ptr_at(fisher_index), out.ptr_at(mean_index))
+        out.version += 1
+
+    def axpby_d(self, a, x_d, b, y_d, count=None, x_index=0, y_index=0):
+        """y = a x + b y on the device (accumulators of main.py:281-289)"""
+        n = int(count if count is not None else y_d.size * (2 if y_d.complex_pairs else 1))
+        check(lib().cg_axpby(self._ctx, float(a), x_d.ptr_at(x_index), float(b), y_d.ptr_at(y_index), n), self._ctx)
+        y_d.version += 1
+        return y_d
+
+    def scale_d(self, y_d, s, count=None, index=0):
+        n = int(count if count is not None else y_d.size * (2 if y_d.complex_pairs else 1))
+        check(lib().cg_scale_dev(self._ctx, y_d.ptr_at(index), n, float(s)), self._ctx)
+        y_d.version += 1
+        return y_d
+
+    def fisher_real_d(self, score, tag="classical_fisher"):
+        """classical Fisher matrix S^T S / B formed on the device and LEFT there (src/sr.py:74)"""
+        S = self.asdevice(_f64(score), tag + "_scores")
+        B, P = S.shape
+        F = self.scratch(tag, (P, P))
+        self._dev_call(lib().cg_fisher_real, S.ptr, int(B), int(P), F.ptr)
+        F.version += 1
+        return F
+
+    def spd_solve_d(self, A_d, b, damping=0.0, center=None, index=0, P=None):
+        """(A - Re(conj(m) m^T) + damping I)^-1 b with A (P,P) at A_d[index:] on the device (factored in a device-side
+        copy); b, m, x are O(P) host vectors.  src/sr.py:88, 102-112."""
+        b = _f64(b).reshape(-1)
+        P = int(P if P is not None else b.size)
+        vec = self.scratch("solve_vec", (4 * P,))
+        host = np.zeros(4 * P)
+        host[:P] = b
+        if center is not None:
+            center = np.asarray(center).reshape(-1)
+            host[P:2 * P] = center.real; host[2 * P:3 * P] = center.imag
+        vec.upload(host)
+        work = self.scratch("solve_matrix", (P * P,))            # factor a copy: the caller's matrix stays intact
+        self.axpby_d(1.0, A_d, 0.0, work, count=P * P, x_index=index)
+        self._dev_call(lib().cg_spd_solve, work.ptr, P, float(damping),
+                       vec.ptr_at(P) if center is not None else None, vec.ptr_at(2 * P) if center is not None else None,
+                       vec.ptr_at(0), vec.ptr_at(3 * P))
+        return vec.numpy(3 * P, P)
 
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):

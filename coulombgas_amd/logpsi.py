@@ -78,13 +78,21 @@ def _draw_v(key, shape):
     return rng.standard_normal(shape)
 
 
+def _is_device(a):
+    return not isinstance(a, np.ndarray) and hasattr(a, "ptr")
+
+
 def make_logpsi_grad_laplacian(logpsi, forloop=True, hutchinson=False, logphi=None, logjacdet=None):
     """src/logpsi.py:55-172.  `forloop` selects between two algebraically identical reference
-    variants (:86-100) and has no effect here."""
+    variants (:86-100) and has no effect here.  With DeviceArray arguments the results are DeviceArrays too and the
+    probe is drawn on the device (cg_randn) unless `key` is an explicit probe array."""
     wf = logpsi.wf
 
     def logpsi_vmapped(x, params, state_idx):
-        out = wf.engine(x, params).logpsi(x, state_idx)
+        eng = wf.engine(x, params)
+        if _is_device(x):
+            return eng.logpsi_d(x, state_idx if _is_device(state_idx) else eng.asdevice(state_idx, "sidx", np.int32))
+        out = eng.logpsi(x, state_idx)
         return out[..., 0] + 1j * out[..., 1]
 
     if not hutchinson:
@@ -95,8 +103,19 @@ def make_logpsi_grad_laplacian(logpsi, forloop=True, hutchinson=False, logphi=No
         mode = _lib.CG_LAP_HUTCHINSON_SPLIT
 
     def logpsi_grad_laplacian(x, params, state_indices, key):
+        eng = wf.engine(x, params)
+        if _is_device(x):
+            v_d = None
+            if hutchinson:
+                if isinstance(key, np.ndarray) and key.shape == tuple(x.shape):
+                    v_d = eng.asdevice(key, "probe")
+                else:
+                    from .mcmc import _seed_of
+                    v_d = eng.randn_d("probe", x.shape, _seed_of(key))
+            s_d = state_indices if _is_device(state_indices) else eng.asdevice(state_indices, "sidx", np.int32)
+            return eng.grad_laplacian_d(x, s_d, mode, v_d)
         v = _draw_v(key, np.shape(x)) if hutchinson else None
-        return wf.engine(x, params).grad_laplacian(x, state_indices, mode, v)
+        return eng.grad_laplacian(x, state_indices, mode, v)
 
     logpsi_vmapped.wf = logpsi_grad_laplacian.wf = wf
     logpsi_grad_laplacian.mode = mode

@@ -12,19 +12,30 @@ def _seed_of(key):
     return int(key)
 
 
-def mcmc(logp_fn, x_init, key, mc_steps, mc_stddev=0.02, noise=None, unif=None, walker_offset=0, comm=None):
+def mcmc(logp_fn, x_init, key, mc_steps, mc_stddev=0.02, noise=None, unif=None, walker_offset=0, comm=None, wrap_L=None):
     """src/MCMC.py:7-40.  `logp_fn` must be `logp.bind(params_flow, state_indices)` (make_logp): the
     reference passes `lambda x: logp(x, params_flow, state_indices)` (src/VMC.py:23); an opaque Python
     callable cannot run inside the GPU chain, and there is no CPU fallback.
     `key`: int / SeedSequence / Generator seeding the in-kernel Philox stream; or pass `noise`
     (steps,B,n,dim) and `unif` (steps,B) to replace jax.random.normal/uniform (src/MCMC.py:26,29).
+    x_init: numpy array (a new array is returned) or DeviceArray (advanced in place and returned).
+    wrap_L: also apply x -= L floor(x / L) (src/VMC.py:24) before anything leaves the device.
     Returns x, accept_rate (mean over ranks, src/MCMC.py:39)."""
     if not hasattr(logp_fn, "wf"):
         raise TypeError("mcmc needs logp.bind(params_flow, state_indices) from make_logp, got %r" % (logp_fn,))
     eng = logp_fn.wf.engine(x_init, logp_fn.params)
-    x, _, nacc = eng.mcmc(x_init, logp_fn.state_indices, mc_steps, mc_stddev, seed=_seed_of(key),
-                          walker_offset=walker_offset, noise=noise, unif=unif)
-    batch = int(np.prod(np.shape(x_init)[:-2]))
+    lead = np.shape(x_init)[:-2]
+    batch = int(np.prod(lead))
+    on_device = not isinstance(x_init, np.ndarray) and hasattr(x_init, "ptr")
+    if on_device:
+        x_d = x_init
+    else:
+        x_d = eng.asdevice(np.asarray(x_init, dtype=np.float64).reshape((batch,) + tuple(np.shape(x_init)[-2:])), "x_chain")
+    s_d = eng.asdevice(np.asarray(logp_fn.state_indices).reshape(batch, -1), "sidx", np.int32)
+    nacc = eng.mcmc_d(x_d, s_d, mc_steps, mc_stddev, seed=_seed_of(key), walker_offset=walker_offset, noise=noise, unif=unif)
+    if wrap_L is not None:
+        eng.wrap_d(x_d)
     accept_rate = nacc / (mc_steps * batch) if mc_steps * batch else 0.0
     accept_rate = (comm or get_comm()).pmean(accept_rate)
+    x = x_d if on_device else eng.to_host(x_d).reshape(lead + tuple(np.shape(x_init)[-2:]))
     return x, accept_rate

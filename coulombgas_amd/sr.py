@@ -3,8 +3,8 @@
 
 The Fisher matrices are where the work is: the quantum one, Re(S^H S)/B over the per-sample scores
 S = d log Psi / d theta (src/logpsi.py:183-203), is formed on the GPU (cg_quantum_fisher: reverse passes for the
-scores, f64 MFMA SYRK, all on the device).  The (P x P) damped solves and the norm clip (src/sr.py:102-117) are host
-LAPACK calls once per optimisation step.  The classical score function (the autoregressive Transformer, outside the
+scores, f64 MFMA SYRK, all on the device), and the centred, damped solve runs there too (cg_spd_solve: blocked Cholesky +
+triangular solves); the norm clip (src/sr.py:102-117) is O(P) host arithmetic.  The classical score function (the autoregressive Transformer, outside the
 accelerated path) is supplied by the caller and returns a (B, P_van) array (or a pytree of arrays with a leading
 batch axis, ravelled in sorted-key order like jax's ravel_pytree)."""
 from collections import namedtuple
@@ -41,27 +41,43 @@ def _ravel_batched(score):
     return np.concatenate([_ravel_batched(score[k]) for k in keys], axis=1)
 
 
+_warned_indefinite = [False]
+
+
 def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, center=None):
     """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  With an engine the
-    damped solve runs on the GPU (cg_spd_solve: shift, blocked Cholesky, both triangular solves); host LAPACK otherwise
-    (small systems, and if round-off made the matrix indefinite).  center: complex score mean m; the matrix solved is
+    damped solve runs on the GPU (cg_spd_solve: centring, shift, blocked Cholesky, both triangular solves); host LAPACK for
+    small systems (P < 512).  The ONLY device outcome that is handled here is CG_ERR_STATE = "the shifted matrix is not
+    positive definite" (round-off on a nearly singular Fisher matrix): the reference's jax.scipy.linalg.solve is a general
+    LU solve and would still return a result, so that case goes to the host's symmetric-indefinite solver, once with a
+    warning.  Every other device error propagates.  center: complex score mean m; the matrix solved is
     F - Re(conj(m) m^T) (src/sr.py:88)."""
     from scipy.linalg import solve, LinAlgError
+    from ._lib import CoulombGasError, CG_ERR_STATE
     upd = None
-    if engine is not None and hasattr(engine, "spd_solve") and fisher.shape[0] >= 512:
+    on_device = not isinstance(fisher, np.ndarray) and hasattr(fisher, "ptr")
+    if on_device or (engine is not None and hasattr(engine, "spd_solve") and fisher.shape[0] >= 512):
         try:
-            upd = engine.spd_solve(fisher, grads_raveled, damping, center)
-            if not np.isfinite(upd).all():
-                upd = None
-        except Exception:
-            upd = None
+            if on_device:          # the matrix never leaves HBM (the solver factors a device-side copy)
+                upd = fisher.eng.spd_solve_d(fisher.base, grads_raveled, damping, center, index=fisher.index, P=fisher.shape[0])
+            else:
+                upd = engine.spd_solve(fisher, grads_raveled, damping, center)
+        except CoulombGasError as e:
+            if e.code != CG_ERR_STATE:
+                raise
+            if not _warned_indefinite[0]:
+                import warnings
+                warnings.warn("SR: damped Fisher matrix not positive definite on the device (%s); symmetric-indefinite host solve" % e)
+                _warned_indefinite[0] = True
+            if on_device:
+                fisher = np.asarray(fisher)
     if upd is None:
         if center is not None:                     # src/sr.py:88
             fisher = fisher - np.outer(center.real, center.real) - np.outer(center.imag, center.imag)
         fisher = fisher + damping * np.eye(fisher.shape[0])
         try:                                       # Fisher + damping I is symmetric positive definite: Cholesky
             upd = solve(fisher, grads_raveled, assume_a="pos")
-        except LinAlgError:                        # (round-off made it indefinite: fall back to the symmetric solver)
+        except LinAlgError:                        # (round-off made it indefinite: the symmetric solver)
             upd = solve(fisher, grads_raveled, assume_a="sym")
     gnorm = float(np.sum(grads_raveled * upd))
     scale = min(np.sqrt(max_norm / gnorm), 1.0) if gnorm > 0 else 1.0
@@ -93,24 +109,26 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
     last_engine = [None]
 
     def fishers_fn(params_van, params_flow, state_indices, x):
+        """src/sr.py:65-84.  The matrices are formed, all-reduced and returned in HBM (DeviceArrays on a GPU engine): the
+        (P x P) quantum Fisher matrix and the mean score share one buffer and one all-reduce; nothing of size O(B P) or
+        O(P^2) visits the host."""
         cm = comm or get_comm()
         eng = wf.engine(x, params_flow)
         last_engine[0] = eng
         classical_fisher = None
         if classical_score_fn is not None:
             cs = _ravel_batched(classical_score_fn(params_van, state_indices))
-            cf = eng.fisher_real(cs) if hasattr(eng, "fisher_real") else cs.T.dot(cs) / cs.shape[0]
-            classical_fisher = cm.pmean(cf)
-        if getattr(cm, "world", 1) == 1:             # nothing to average: hand the engine's matrix on as it is
-            try:
-                qf, qmean = eng.quantum_fisher(x, state_indices, reuse_out=True)
-            except TypeError:                        # an engine without the buffer option
-                qf, qmean = eng.quantum_fisher(x, state_indices)
-            return classical_fisher, qf, qmean
-        qf, qmean = eng.quantum_fisher(x, state_indices)
-        packed = cm.pmean(np.concatenate([qf.reshape(-1), qmean.real, qmean.imag]))      # one all-reduce
-        P = qmean.shape[0]
-        return classical_fisher, packed[:P * P].reshape(P, P), packed[P * P:P * P + P] + 1j * packed[P * P + P:]
+            classical_fisher = cm.pmean_d(eng.fisher_real_d(cs))                         # :77-79
+        x_d = eng.asdevice(x, "x")
+        s_d = eng.asdevice(state_indices, "sidx", np.int32)
+        eng.scores_compute_d(x_d, s_d)                                                   # :69-71 (shared with the theta-VJP)
+        P = eng.P
+        pack = eng.scratch("fisher_pack", (P * P + 2 * P,))
+        eng.scores_fisher_d(pack, 0, P * P)
+        cm.pmean_d(pack)                                                                 # :73, :80-82 in one all-reduce
+        qf = eng.view(pack, 0, (P, P))
+        sm = eng.to_host_slice(pack, P * P, 2 * P)
+        return classical_fisher, qf, sm[0::2] + 1j * sm[1::2]
 
     def init_fn(params):
         return EmptyState()

@@ -1,14 +1,21 @@
-"""Host-side mirror of src/VMC.py (+ the jacrev / final-step algebra of main.py:277-298)."""
+"""Host-side mirror of src/VMC.py (+ the jacrev / final-step algebra of main.py:277-298).
+
+Arrays: every closure accepts numpy arrays or `DeviceArray`s (engine.py).  The arithmetic of an optimisation step -- local
+energies, their moments, clip widths, loss weights, theta-gradients -- runs in kernels on device-resident arrays
+(Engine.*_d); the host sees the ten observables and O(P) vectors only."""
 import numpy as np
 from .comm import get_comm
 from .mcmc import mcmc
-from .potential import potential_energy
+
+OBSERVABLES = ("K_mean", "K2_mean", "V_mean", "V2_mean", "E_mean", "E2_mean", "F_mean", "F2_mean", "S_mean", "S2_mean")
+_I_E, _I_F = 4, 6          # positions of <E> and <F> in the moments vector (src/VMC.py:46-53 order)
 
 
 def sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc_steps, mc_stddev, L, comm=None):
     """src/VMC.py:8-25 for ONE device (one process per GPU replaces the pmap).
     key: numpy SeedSequence (or int).  sampler(params_van, key_state, batch) -> (batch, n) int state indices
     (the autoregressive sampler is outside the accelerated path and stays host code).
+    x: numpy array, or a DeviceArray that is advanced in place (the reference donates x, src/VMC.py:11).
     Returns key, state_indices, x (wrapped into [0,L)), accept_rate (pmean'd)."""
     ss = key if isinstance(key, np.random.SeedSequence) else np.random.SeedSequence(int(key))
     key, key_state, key_MCMC = ss.spawn(3)                                    # jax.random.split(key, 3), :20
@@ -16,14 +23,14 @@ def sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc
     state_indices = np.asarray(sampler(params_van, key_state, batch), dtype=np.int32)
     comm = comm or get_comm()
     x, accept_rate = mcmc(logp.bind(params_flow, state_indices), x, key_MCMC, mc_steps, mc_stddev,
-                          walker_offset=comm.rank * batch, comm=comm)
-    x = x - L * np.floor(x / L)                                                # :24
+                          walker_offset=comm.rank * batch, comm=comm, wrap_L=L)     # :23-24 (wrap fused into the call)
     return key, state_indices, x, accept_rate
 
 
 def complex_clip(a, lo, hi):
     """jnp.clip on complex E_loc (src/VMC.py:73) = minimum(maximum(a, lo), hi) with the lexicographic
-    complex order of the JAX generation the reference targets."""
+    complex order of the JAX generation the reference targets.  Host restatement of k_clip_weights,
+    used by the value path of quantum_lossfn only."""
     a = np.asarray(a, dtype=np.complex128)
     lt = lambda p, q: (p.real < q.real) | ((p.real == q.real) & (p.imag < q.imag))
     lo_c, hi_c = np.complex128(lo), np.complex128(hi)
@@ -39,49 +46,60 @@ def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, 
 
     def observable_and_lossfn(params_van, params_flow, state_indices, x, key):
         cm = comm or get_comm()
-        pmean = cm.pmean
-        logp_states = np.asarray(log_prob(params_van, state_indices), dtype=np.float64)
-        grad, laplacian = logpsi_grad_laplacian(x, params_flow, state_indices, key)
-        kinetic = -laplacian - (grad ** 2).sum(axis=(-2, -1))                  # :39
         eng = wf.engine(x, params_flow)
-        potential = potential_energy(x, kappa, G, L, rs, engine=eng) + Vconst  # :40
-        Eloc = kinetic + potential
-        Floc = logp_states / beta + Eloc.real
-
-        vals = np.array([kinetic.real.mean(), (kinetic.real ** 2).mean(),
-                         potential.mean(), (potential ** 2).mean(),
-                         Eloc.real.mean(), (Eloc.real ** 2).mean(),
-                         Floc.mean(), (Floc ** 2).mean(),
-                         -logp_states.mean(), (logp_states ** 2).mean()])
-        vals = pmean(vals)                                                      # :44-53 (one packed all-reduce)
-        names = ["K_mean", "K2_mean", "V_mean", "V2_mean", "E_mean", "E2_mean", "F_mean", "F2_mean", "S_mean", "S2_mean"]
-        observable = {k: float(v) for k, v in zip(names, vals)}
+        eng.set_ewald(kappa, G, rs)
+        x_d = eng.asdevice(x, "x")
+        s_d = eng.asdevice(state_indices, "sidx", np.int32)
+        logp_states = np.asarray(log_prob(params_van, state_indices), dtype=np.float64)     # classical model: host side
+        grad, laplacian = logpsi_grad_laplacian(x_d, params_flow, s_d, key)                  # :35, stays on the device
+        V = eng.ewald_d(x_d)                                                                 # :40
+        lps_d = eng.asdevice(logp_states, "logp_states") if logp_states.any() else None
+        Eloc, Floc, mom = eng.local_energy_d(grad, laplacian, V, lps_d, Vconst, beta)       # :39-42 + local means of :46-53
+        cm.pmean_d(mom)                                                                      # :44-53, one 10-double all-reduce
+        vals = eng.to_host(mom)
+        observable = {k: float(v) for k, v in zip(OBSERVABLES, vals)}
         F_mean, E_mean = observable["F_mean"], observable["E_mean"]
-        B = Eloc.shape[0]
+        B = int(np.shape(x)[0])
+        cache = {}
+
+        def tv_E():
+            """pmean(mean |E_loc - <E>|) of :72, computed once per call of observable_and_lossfn, on the device"""
+            if "tvE" not in cache:
+                cache["tvE"] = cm.pmean_d(eng.abs_dev_d(Eloc, (mom, _I_E), "tv_E"))
+            return cache["tvE"]
 
         def classical_lossfn(params_van):
             lps = np.asarray(log_prob(params_van, state_indices), dtype=np.float64)
-            tv = pmean(float(np.abs(Floc - F_mean).mean()))                    # :63
-            Floc_clipped = np.clip(Floc, F_mean - 5.0 * tv, F_mean + 5.0 * tv)
+            Floc_h = eng.to_host(Floc)
+            tv = cm.pmean(float(np.abs(Floc_h - F_mean).mean()))                           # :63
+            Floc_clipped = np.clip(Floc_h, F_mean - 5.0 * tv, F_mean + 5.0 * tv)
             classical_lossfn.weights = Floc_clipped / B      # d gradF_phi / d logp_states[b]
             classical_lossfn.score_weights = np.full(B, 1.0 / B)
             return float((lps * Floc_clipped).mean()), float(lps.mean())
 
         def quantum_lossfn(params_flow):
-            logpsix = logpsi(x, params_flow, state_indices)
-            tv = pmean(float(np.abs(Eloc - E_mean).mean()))                    # :72
-            Eloc_clipped = complex_clip(Eloc, E_mean - 5.0 * tv, E_mean + 5.0 * tv)
+            """(gradF_theta, quantum_score) values of :69-76 (diagnostic path: downloads log Psi and E_loc)"""
+            logpsix = np.asarray(logpsi(x_d, params_flow, s_d))
+            tv = float(eng.to_host(tv_E())[0])
+            Eloc_clipped = complex_clip(eng.to_host(Eloc), E_mean - 5.0 * tv, E_mean + 5.0 * tv)
             quantum_lossfn.Eloc_clipped = Eloc_clipped
             return float(2 * (logpsix * Eloc_clipped.conj()).real.mean()), float(2 * logpsix.real.mean())
 
-        def quantum_grad(params_flow, as_pytree=True):
+        def quantum_grad(params_flow, as_pytree=True, reduce=False):
             """(d gradF_theta / d theta, d quantum_score / d theta) = jax.jacrev(quantum_lossfn)(params_flow), main.py:278.
-            2 mean Re(logPsi conj(Ec)) -> weights (2/B) Re Ec on Re logPsi and (2/B) Im Ec on Im logPsi."""
-            tv = pmean(float(np.abs(Eloc - E_mean).mean()))
-            Ec = complex_clip(Eloc, E_mean - 5.0 * tv, E_mean + 5.0 * tv)
+            2 mean Re(logPsi conj(Ec)) -> weights (2/B) Re Ec on Re logPsi and (2/B) Im Ec on Im logPsi; the score gradient is
+            2 Re mean_b S_b.  reduce=True also applies the pmean of main.py:280 (one 3P-double all-reduce on the device)."""
             e = wf.engine(x, params_flow)
-            g = e.param_vjp(x, state_indices, 2.0 * Ec.real / B, 2.0 * Ec.imag / B)
-            s = e.param_vjp(x, state_indices, np.full(B, 2.0 / B), np.zeros(B))
+            P = e.P
+            w_re, w_im = e.clip_weights_d(Eloc, (mom, _I_E), tv_E(), 2.0 / B, "w")          # :73 + weights
+            e.scores_compute_d(x_d, s_d)
+            gs = e.scratch("grad_score", (3 * P,))
+            e.scores_vjp_d(w_re, w_im, gs, 0)
+            e.scores_mean_d(gs, P)
+            if reduce:
+                cm.pmean_d(gs)
+            h = e.to_host(gs)
+            g, s = h[:P].copy(), 2.0 * h[P::2]
             if not as_pytree:
                 return g, s
             dim = np.shape(x)[-1]

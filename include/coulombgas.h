@@ -141,6 +141,38 @@ int cg_scores_compute(cg_ctx* ctx, const double* x, const int32_t* state_idx, in
 int cg_scores_vjp(cg_ctx* ctx, const double* w_re, const double* w_im, double* g_theta);
 int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
 
+/* mean over the batch of the resident scores: score_mean (P,2) = mean_b S[b]  (src/sr.py:70 before its pmean; also
+ * 1/2 of d/dtheta of quantum_score = 2 mean Re logPsi, src/VMC.py:75, main.py:278) */
+int cg_scores_mean(cg_ctx* ctx, double* score_mean);
+
+/* ---- local energy and loss weights on the device (K8) ----------------------------------------------------- */
+
+/* src/VMC.py:39-58 for ONE device, before the pmean: from grad (B,n,dim,2), lap (B,2) of cg_grad_laplacian and V (B) of
+ * cg_ewald:  kinetic = -lap - sum grad^2 (complex square), E_loc = kinetic + V + Vconst, F_loc = logp_states / beta + Re E_loc.
+ *   logp_states  nullable (B): log-probabilities of the sampled occupations (NULL = zeros)
+ *   eloc (B,2) complex, floc nullable (B)
+ *   moments (10) = local means of [K, K^2, V, V^2, E, E^2, F, F^2, -logp_states, logp_states^2] (real parts), the order of
+ *   src/VMC.py:46-53; the caller all-reduces them (cg_allreduce_mean). */
+int cg_local_energy(cg_ctx* ctx, const double* grad, const double* lap, const double* V, const double* logp_states, int B,
+                    double Vconst, double beta, double* eloc, double* floc, double* moments);
+/* out (1) = mean_b |e_b - center[0]|: the clip width tv before its pmean (src/VMC.py:63 real F_loc: is_complex 0, e (B);
+ * src/VMC.py:72 complex E_loc: is_complex 1, e (B,2)).  center is read from memory when the kernel runs (device-pointer
+ * mode: the all-reduced mean never visits the host). */
+int cg_abs_dev(cg_ctx* ctx, const double* e, int B, int is_complex, const double* center, double* out);
+/* Loss weights behind jax.jacrev of the loss closures (src/VMC.py:64-66, 73-75; main.py:277-278):
+ *   clipped = clip(e, center - 5 tv, center + 5 tv)   (complex: lexicographic order of the reference's JAX generation)
+ *   w_re = scale * Re clipped, w_im = scale * Im clipped (complex only); quantum loss: scale = 2 / B, then
+ *   cg_scores_vjp / cg_param_vjp with (w_re, w_im) give d gradF_theta / d theta. */
+int cg_clip_weights(cg_ctx* ctx, const double* e, int B, int is_complex, const double* center, const double* tv, double scale,
+                    double* w_re, double* w_im);
+/* count standard normals from the in-library Philox4x32-10 stream (seed, offset + i): the Hutchinson probe
+ * jax.random.normal(key, x.shape) of src/logpsi.py:110 without a host round trip. */
+int cg_randn(cg_ctx* ctx, double* out, size_t count, uint64_t seed, uint64_t offset);
+/* y = a x + b y for DEVICE pointers in both pointer modes: the accumulators of main.py:281-289 kept in HBM. */
+int cg_axpby(cg_ctx* ctx, double a, const double* x_dev, double b, double* y_dev, size_t count);
+/* buf *= s for a DEVICE pointer (both pointer modes) */
+int cg_scale_dev(cg_ctx* ctx, double* buf_dev, size_t count, double s);
+
 /* Classical Fisher matrix of the SR optimizer (src/sr.py:36, 74) on the device: F (P,P) = S^T S / B for a real (B,P) score
  * matrix, f64 MFMA. */
 int cg_fisher_real(cg_ctx* ctx, const double* S, int B, int P, double* F);

@@ -11,7 +11,7 @@
  *   - logp = 2 Re log Psi                                             src/logpsi.py:174-181
  *   - Metropolis chain with supplied normal / uniform draws           src/MCMC.py:22-39
  *   - pair-form Ewald sum                                             src/potential.py:36-77
- * OpenMP over walkers.  Used (a) as bench.py's cpu_baseline ("port": the reference's JAX path cannot run on
+ * OpenMP over walkers, SIMD over the n*d tangents.  Used (a) as bench.py's cpu_baseline ("port": the reference's JAX path cannot run on
  * this image), (b) as a second, AD-free checker for the GPU results at sizes torch.func is too slow for.
  *
  * PARITY PINNING: this file is validated against oracle/cg_ref.py (tests/test_oracle_kat.py), which in turn is
@@ -79,7 +79,13 @@ int cgo_num_params(int dim, int depth, int hs, int ht) {
 static inline double softplus(double u) { return fmax(u, 0.0) + log1p(exp(-fabs(u))); }
 static inline double sigmoid(double u) { double e = exp(-fabs(u)); return u >= 0 ? 1.0 / (1.0 + e) : e / (1.0 + e); }
 
-/* Flow value z (n*dim) and, if J != NULL, dense forward-mode Jacobian J (N x N row-major, J[out][in]). */
+/* Flow value z (n*dim) and, if J != NULL, dense forward-mode Jacobian J (N x N row-major, J[out][in]).
+ * The tangent loops run over the contiguous q axis so that the compiler vectorises them; target_clones builds AVX-512,
+ * AVX2 and baseline versions and the loader picks one for the CPU it runs on (the .so is built in one container and
+ * timed on another machine). */
+#if defined(__GNUC__) && defined(__x86_64__) && !defined(CGO_NO_CLONES)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
 static void flow_forward(const Model* m, const double* x, double* z, double* J) {
     const int n = m->n, d = m->dim, hs = m->hs, ht = m->ht, N = n * d, P = 2 * d + 1;
     const int NT = J ? N : 0;
@@ -126,23 +132,38 @@ static void flow_forward(const Model* m, const double* x, double* z, double* J) 
         /* f = [sp, mean_k sp, mean_j tp]  src/flow.py:28-37 */
         memset(f, 0, sizeof(double) * n * fmax_);
         if (NT) memset(df, 0, sizeof(double) * (size_t)n * fmax_ * NT);
+        /* mean_k sp (the same for every i: computed once, broadcast) */
+        for (int c = 0; c < ws; ++c) {
+            double mean = 0; for (int k = 0; k < n; ++k) mean += sp[k * wmax_s + c];
+            f[0 * fs + ws + c] = mean / n;
+            if (NT) {
+                double* restrict o = df + ((size_t)0 * fs + ws + c) * NT;
+                for (int k = 0; k < n; ++k) {
+                    const double* restrict src = dsp + ((size_t)k * wmax_s + c) * NT;
+                    for (int q = 0; q < NT; ++q) o[q] += src[q];
+                }
+                for (int q = 0; q < NT; ++q) o[q] /= n;
+            }
+        }
         for (int i = 0; i < n; ++i) {
             for (int c = 0; c < ws; ++c) {
                 f[i * fs + c] = sp[i * wmax_s + c];
-                double mean = 0; for (int k = 0; k < n; ++k) mean += sp[k * wmax_s + c];
-                f[i * fs + ws + c] = mean / n;
-                for (int q = 0; q < NT; ++q) {
-                    df[((size_t)i * fs + c) * NT + q] = dsp[((size_t)i * wmax_s + c) * NT + q];
-                    double dm = 0; for (int k = 0; k < n; ++k) dm += dsp[((size_t)k * wmax_s + c) * NT + q];
-                    df[((size_t)i * fs + ws + c) * NT + q] = dm / n;
+                f[i * fs + ws + c] = f[0 * fs + ws + c];
+                if (NT) {
+                    memcpy(df + ((size_t)i * fs + c) * NT, dsp + ((size_t)i * wmax_s + c) * NT, sizeof(double) * NT);
+                    if (i) memcpy(df + ((size_t)i * fs + ws + c) * NT, df + ((size_t)0 * fs + ws + c) * NT, sizeof(double) * NT);
                 }
             }
             for (int c = 0; c < wt; ++c) {
                 double mean = 0; for (int j = 0; j < n; ++j) mean += tp[((size_t)i * n + j) * wmax_t + c];
                 f[i * fs + 2 * ws + c] = mean / n;
-                for (int q = 0; q < NT; ++q) {
-                    double dm = 0; for (int j = 0; j < n; ++j) dm += dtp[(((size_t)i * n + j) * wmax_t + c) * NT + q];
-                    df[((size_t)i * fs + 2 * ws + c) * NT + q] = dm / n;
+                if (NT) {
+                    double* restrict o = df + ((size_t)i * fs + 2 * ws + c) * NT;
+                    for (int j = 0; j < n; ++j) {
+                        const double* restrict src = dtp + (((size_t)i * n + j) * wmax_t + c) * NT;
+                        for (int q = 0; q < NT; ++q) o[q] += src[q];
+                    }
+                    for (int q = 0; q < NT; ++q) o[q] /= n;
                 }
             }
         }
@@ -153,10 +174,16 @@ static void flow_forward(const Model* m, const double* x, double* z, double* J) 
                 double a = bb[h];
                 for (int c = 0; c < fs; ++c) a += f[i * fs + c] * W[c * hs + h];
                 u[h] = a;
-                for (int q = 0; q < NT; ++q) {
-                    double da = 0;
-                    for (int c = 0; c < fs; ++c) da += df[((size_t)i * fs + c) * NT + q] * W[c * hs + h];
-                    du[(size_t)h * NT + q] = da;
+            }
+            if (NT) {      /* tangents: the q axis innermost and contiguous (SIMD), every tangent carried, zeros included */
+                memset(du, 0, sizeof(double) * (size_t)hs * NT);
+                for (int c = 0; c < fs; ++c) {
+                    const double* restrict dfc = df + ((size_t)i * fs + c) * NT;
+                    for (int h = 0; h < hs; ++h) {
+                        const double w = W[c * hs + h];
+                        double* restrict duh = du + (size_t)h * NT;
+                        for (int q = 0; q < NT; ++q) duh[q] += dfc[q] * w;
+                    }
                 }
             }
             for (int h = 0; h < hs; ++h) {
@@ -183,10 +210,16 @@ static void flow_forward(const Model* m, const double* x, double* z, double* J) 
                         double a = bt[h];
                         for (int c = 0; c < wt; ++c) a += t[c] * Wt[c * ht + h];
                         u[h] = a;
-                        for (int q = 0; q < NT; ++q) {
-                            double da = 0;
-                            for (int c = 0; c < wt; ++c) da += dt[(size_t)c * NT + q] * Wt[c * ht + h];
-                            du[(size_t)h * NT + q] = da;
+                    }
+                    if (NT) {
+                        memset(du, 0, sizeof(double) * (size_t)ht * NT);
+                        for (int c = 0; c < wt; ++c) {
+                            const double* restrict dtc = dt + (size_t)c * NT;
+                            for (int h = 0; h < ht; ++h) {
+                                const double w = Wt[c * ht + h];
+                                double* restrict duh = du + (size_t)h * NT;
+                                for (int q = 0; q < NT; ++q) duh[q] += dtc[q] * w;
+                            }
                         }
                     }
                     for (int h = 0; h < ht; ++h) {

@@ -133,6 +133,103 @@ class EmulEngine:
         sc = self.quantum_score(x, sidx).reshape(-1, self.P)
         return (sc.conj().T @ sc).real / sc.shape[0], sc.mean(axis=0)
 
+    # ---- the device-resident API of coulombgas_amd.engine.Engine with numpy arrays as "device" handles (CPU tests of the
+    # host logic in vmc.py / driver.py / sr.py; the arithmetic below restates the small kernels k_local_energy,
+    # k_abs_dev, k_clip_weights for that purpose -- the GPU tests compare the kernels themselves with the oracle) ----
+    def asdevice(self, a, tag, dtype=np.float64):
+        return np.array(a, dtype=dtype, copy=True, order="C")
+
+    def to_host(self, a):
+        return np.asarray(a)
+
+    def scratch(self, tag, shape, dtype=np.float64, complex_pairs=False):
+        pool = self.__dict__.setdefault("_scratch", {})
+        key = (tag, tuple(shape), bool(complex_pairs))
+        if key not in pool:
+            pool[key] = np.zeros(shape, dtype=np.complex128 if complex_pairs else dtype)
+        return pool[key]
+
+    def mcmc_d(self, x, s, mc_steps, mc_stddev, seed=0, walker_offset=0, noise=None, unif=None):
+        xn, _, nacc = self.mcmc(x, s, mc_steps, mc_stddev, seed, walker_offset, noise, unif)
+        x[...] = xn
+        return nacc
+
+    def wrap_d(self, x):
+        x -= self.L * np.floor(x / self.L)
+        return x
+
+    def randn_d(self, tag, shape, seed, offset=0):
+        return np.random.default_rng([int(seed) % (2 ** 63), int(offset)]).standard_normal(shape)
+
+    def logpsi_d(self, x, s):
+        out = self.logpsi(x, s)
+        return out[..., 0] + 1j * out[..., 1]
+
+    def grad_laplacian_d(self, x, s, mode, v=None):
+        return self.grad_laplacian(x, s, mode, v)
+
+    def ewald_d(self, x):
+        return self.ewald(x)
+
+    def local_energy_d(self, grad, lap, V, logp_states, Vconst, beta):
+        kin = -lap - (grad ** 2).sum(axis=(-2, -1))
+        pot = V + Vconst
+        eloc = kin + pot
+        lps = np.zeros(V.shape) if logp_states is None else logp_states
+        floc = lps / beta + eloc.real
+        mom = np.array([kin.real.mean(), (kin.real ** 2).mean(), pot.mean(), (pot ** 2).mean(), eloc.real.mean(), (eloc.real ** 2).mean(),
+                        floc.mean(), (floc ** 2).mean(), -lps.mean(), (lps ** 2).mean()])
+        return eloc, floc, mom
+
+    def abs_dev_d(self, e, center, tag="tv"):
+        return np.array([np.abs(e - center[0][center[1]]).mean()])
+
+    def clip_weights_d(self, e, center, tv, scale, tag="w"):
+        c, t = float(center[0][center[1]]), float(tv[0])
+        lo, hi = c - 5 * t, c + 5 * t
+        if not np.iscomplexobj(e):
+            return scale * np.clip(e, lo, hi), None
+        re, im = e.real.copy(), e.imag.copy()
+        m = (re < lo) | ((re == lo) & (im < 0)); re[m] = lo; im[m] = 0.0
+        m = (hi < re) | ((hi == re) & (0 < im)); re[m] = hi; im[m] = 0.0
+        return scale * re, scale * im
+
+    def scores_compute_d(self, x, s):
+        self._S = self.quantum_score(x, s).reshape(-1, self.P)
+
+    def scores_vjp_d(self, w_re, w_im, out, out_index=0):
+        out[out_index:out_index + self.P] = (w_re[:, None] * self._S.real + w_im[:, None] * self._S.imag).sum(axis=0)
+
+    def scores_mean_d(self, out, out_index=0):
+        m = self._S.mean(axis=0)
+        out[out_index:out_index + 2 * self.P:2] = m.real; out[out_index + 1:out_index + 2 * self.P:2] = m.imag
+
+    def scores_fisher_d(self, out, fisher_index, mean_index):
+        out[fisher_index:fisher_index + self.P ** 2] = ((self._S.conj().T @ self._S).real / self._S.shape[0]).ravel()
+        self.scores_mean_d(out, mean_index)
+
+    def axpby_d(self, a, x, b, y, count=None, x_index=0, y_index=0):
+        xf, yf = x.reshape(-1), y.reshape(-1)
+        n = yf.size - y_index if count is None else count
+        yf[y_index:y_index + n] = a * xf[x_index:x_index + n] + (b * yf[y_index:y_index + n] if b != 0 else 0.0)
+        return y
+
+    def scale_d(self, y, s, count=None, index=0):
+        yf = y.reshape(-1)
+        n = yf.size - index if count is None else count
+        yf[index:index + n] *= s
+        return y
+
+    def fisher_real_d(self, score, tag="classical_fisher"):
+        S = np.asarray(score, dtype=np.float64)
+        return S.T @ S / S.shape[0]
+
+    def view(self, base, index, shape):
+        return base.reshape(-1)[index:index + int(np.prod(shape))].reshape(shape)
+
+    def to_host_slice(self, a, start, count):
+        return np.array(a.reshape(-1)[start:start + count])
+
     def close(self):
         pass
 

@@ -5,6 +5,8 @@ reference): inputs + expected outputs in fp64.  Run once in the build container;
   golden_n7_d3.npz    the reference tests' shape (tests/test_logpsi.py:30-31; depth 2, spsize = tpsize = 16), L = 1.234
   golden_n13_d2.npz   BASELINE configs 1-3 shape, init-like N(0,0.01^2) weights
   golden_n29_d2.npz   shipped trained flow parameters (data/n_29_..._rs_10.0, epoch 3000) on 2 shipped walkers
+  golden_n57_d2.npz, golden_n29_d2_rs1.npz   (--large) BASELINE configs 5 and 4: shipped parameters + walkers of
+                      data/n_57_..._rs_10.0 (Emax 49) and data/n_29_..._rs_1.0; Hutchinson variants only
 each: x, state_idx, theta, sp_indices -> z, J, half_logdetJ, logphi, grad/lap (exact), lap (Hutchinson-split and full for the
 stored probe v), Ewald V, theta-VJP for stored weights, a 5-step Metropolis trajectory for stored noise.
 """
@@ -67,7 +69,21 @@ def make(name, n, dim, hs, ht, L, theta, x, sidx, sp, rs, seed, exact=True):
     print(name, "%.1fs" % (time.time() - t0), "rate", rate)
 
 
+def make_large():
+    """BASELINE configs 4 and 5: shipped trained parameters + shipped walkers at n = 57 (rs = 10, Emax = 49) and n = 29 at
+    rs = 1.  The exact AD Laplacian is minutes per walker there: Hutchinson variants only."""
+    rng = np.random.default_rng(20261004)
+    d = np.load(os.path.join(HERE, "shipped_n57_rs10.npz"))
+    n = 57; L = box_length(n, 2); sp = orbitals(2, 49)
+    make("golden_n57_d2.npz", n, 2, 16, 16, L, d["theta"], d["x"][:2], state_indices(rng, 2, n, sp.shape[0]), sp, 10.0, 4, exact=False)
+    d = np.load(os.path.join(HERE, "shipped_n29_rs1.npz"))
+    n = 29; L = box_length(n, 2); sp = orbitals(2, 25)
+    make("golden_n29_d2_rs1.npz", n, 2, 16, 16, L, d["theta"], d["x"][:2], state_indices(rng, 2, n, sp.shape[0]), sp, 1.0, 5, exact=False)
+
+
 if __name__ == "__main__":
+    if "--large" in sys.argv:
+        make_large(); sys.exit(0)
     rng = np.random.default_rng(20261003)
     # n=7, d=3 (reference test shape)
     n, dim, L = 7, 3, 1.234

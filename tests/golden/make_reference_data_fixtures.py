@@ -4,7 +4,7 @@ Generates the DATA fixtures that come from the reference tree (run once, in the 
 container where /root/reference is mounted; the outputs are committed, this script never
 runs on the GPU box):
 
-  orbitals_dim2_Emax{25,36,49}.npy   twisted, sorted and reversed single-particle table
+  coulombgas_amd/data/orbitals_dim2_Emax{25,36,49}.npy   (shipped with the package) twisted, sorted and reversed single-particle table
                                      = `sp_indices_twist` of main.py:79-90 (twist 1/4,1/4)
   orbitals_dim3_Emax60.npy           untwisted `sp_orbitals(3)[0]` used by the reference tests
                                      (tests/test_slater.py:17, tests/test_logpsi.py:33)
@@ -24,6 +24,7 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
+DATA = os.path.join(os.path.dirname(os.path.dirname(HERE)), "coulombgas_amd", "data")     # orbital tables ship with the package
 
 CHILD = r"""
 import importlib.util, numpy as np, sys, json
@@ -100,9 +101,9 @@ if __name__ == "__main__":
     van_fixture(os.path.join(d, "epoch_003000.pkl"), "params_van", "shipped_n29_rs10_van.npz", {})
     for Emax in (25, 36, 49):
         t = twisted_table(2, Emax, (0.25, 0.25))
-        np.save(os.path.join(HERE, "orbitals_dim2_Emax%d.npy" % Emax), t)
+        np.save(os.path.join(DATA, "orbitals_dim2_Emax%d.npy" % Emax), t)
         print("Emax", Emax, t.shape)
-    np.save(os.path.join(HERE, "orbitals_dim3_Emax60.npy"), legacy_sp_orbitals(3, 60).astype(np.float64))
+    np.save(os.path.join(DATA, "orbitals_dim3_Emax60.npy"), legacy_sp_orbitals(3, 60).astype(np.float64))
     shipped(29, "10.0", 3000, 512, "shipped_n29_rs10.npz")
     shipped(29, "1.0", 3000, 512, "shipped_n29_rs1.npz")
     shipped(57, "10.0", 5000, 256, "shipped_n57_rs10.npz")

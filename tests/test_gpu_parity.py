@@ -586,3 +586,148 @@ def test_shipped_model_reproduces_published_energies():
     assert 0.3 < acc < 0.6
     assert abs(np.mean(E) - row[3]) < 0.01 * abs(row[3]), (np.mean(E), row[3])
     assert abs(np.mean(F) - row[1]) < 0.01 * abs(row[1]), (np.mean(F), row[1])
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident optimisation step (K8 eloc_reduce, clip weights, scores, Fisher, solve all in HBM)
+# ---------------------------------------------------------------------------------------------
+def test_local_energy_kernels_against_oracle():
+    """cg_local_energy / cg_abs_dev / cg_clip_weights (src/VMC.py:39-58, 63-64, 72-73) against the oracle's
+    observables_and_weights on supplied grad / lap / V, including a batch that is not a multiple of the 16 walkers a
+    workgroup handles, values on both clip bounds, and the NULL logp_states (zeros) form."""
+    from oracle import cg_ref as R
+    from coulombgas_amd.engine import Engine, DeviceArray
+    n, dim, B = 7, 2, 77
+    L = box_length(n, dim)
+    rng = np.random.default_rng(5)
+    eng = Engine(n, dim, 2, 16, 16, L, orbitals(dim))
+    grad = rng.standard_normal((B, n, dim)) + 1j * rng.standard_normal((B, n, dim))
+    lap = 3.0 * rng.standard_normal(B) + 1j * rng.standard_normal(B)
+    lap[:6] *= 40.0                                                   # outliers: both clip bounds are hit
+    V = rng.standard_normal(B)
+    Vconst, beta = -1.75, 1 / (4 * 0.15)
+    for lps in (-5.0 + rng.standard_normal(B), None):
+        g_d = eng.scratch("t_grad", (B, n, dim), complex_pairs=True).upload(np.stack([grad.real, grad.imag], axis=-1))
+        l_d = eng.scratch("t_lap", (B,), complex_pairs=True).upload(np.stack([lap.real, lap.imag], axis=-1))
+        V_d = DeviceArray.from_numpy(eng, V)
+        lps_d = None if lps is None else DeviceArray.from_numpy(eng, lps)
+        eloc, floc, mom = eng.local_energy_d(g_d, l_d, V_d, lps_d, Vconst, beta)
+        lps_r = np.zeros(B) if lps is None else lps
+        robs, rE, rF, rFc, rEc = R.observables_and_weights(R.T(lps_r), torch.as_tensor(grad), torch.as_tensor(lap), R.T(V), Vconst, beta)
+        keys = ("K_mean", "K2_mean", "V_mean", "V2_mean", "E_mean", "E2_mean", "F_mean", "F2_mean", "S_mean", "S2_mean")
+        m = np.asarray(mom)
+        for k, v in zip(keys, m):
+            assert v == pytest.approx(float(robs[k]), rel=1e-12, abs=1e-12), k
+        assert np.abs(np.asarray(eloc) - rE.numpy()).max() < 1e-12 * np.abs(rE.numpy()).max()
+        assert np.abs(np.asarray(floc) - rF.numpy()).max() < 1e-12 * np.abs(rF.numpy()).max()
+        tvE = eng.abs_dev_d(eloc, (mom, 4), "t_tvE")
+        assert float(np.asarray(tvE)[0]) == pytest.approx(float((rE - robs["E_mean"]).abs().mean()), rel=1e-12)
+        w_re, w_im = eng.clip_weights_d(eloc, (mom, 4), tvE, 2.0 / B, "t_w")
+        Ec = rEc.numpy()
+        assert (Ec != rE.numpy()).sum() >= 2                          # the clip is active in this sample
+        assert np.abs(np.asarray(w_re) - 2.0 / B * Ec.real).max() < 1e-13 * np.abs(Ec).max()
+        assert np.abs(np.asarray(w_im) - 2.0 / B * Ec.imag).max() < 1e-13 * np.abs(Ec).max()
+        tvF = eng.abs_dev_d(floc, (mom, 6), "t_tvF")
+        assert float(np.asarray(tvF)[0]) == pytest.approx(float((rF - robs["F_mean"]).abs().mean()), rel=1e-12)
+        wf_re, _ = eng.clip_weights_d(floc, (mom, 6), tvF, 1.0 / B, "t_wf")
+        assert np.abs(np.asarray(wf_re) - rFc.numpy() / B).max() < 1e-13 * np.abs(rFc.numpy()).max()
+    # in-library normal stream for the Hutchinson probe: deterministic, offset = position in the stream, N(0,1) moments
+    a = np.asarray(eng.randn_d("t_r1", (4096, 16), seed=11, offset=0)).ravel()
+    b = np.asarray(eng.randn_d("t_r2", (4096, 16), seed=11, offset=0)).ravel()
+    c = np.asarray(eng.randn_d("t_r3", (1000,), seed=11, offset=500))
+    assert np.array_equal(a, b) and np.array_equal(c, a[500:1500])
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02 and abs((a ** 4).mean() - 3.0) < 0.15
+    eng.close()
+
+
+def test_device_resident_step_equals_host_array_step():
+    """One optimisation step of main.py:270-307 with the walkers as a DeviceArray (nothing of size O(B) or O(P^2) crosses
+    PCIe) gives the numbers of the same step fed with numpy arrays: observables, theta-gradient, score, Fisher matrix,
+    SR update -- and the accumulated Fisher matrix over two accumulation steps is the mean of the two."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import DeviceArray
+    case = (13, 2, 16, 16, None, 0.1, 0.05)
+    n, dim = case[:2]
+    B = 48
+    s = _setup(case, B, seed=23)
+    rng = s["rng"]
+    L, rs, kappa, beta = s["L"], 10.0, 10, 1 / (4 * 0.15)
+    G = cg.kpoints(dim, 15)
+    Vconst = n * rs / L * cg.Madelung(dim, kappa, G)
+    lps = -3.0 + rng.standard_normal(B)
+    log_prob = lambda pv, si: lps
+    v = rng.standard_normal(s["x"].shape)
+    lp0 = cg.make_logpsi(s["flow"], s["sp"], L)
+    logphi, logjac = cg.make_logphi_logjacdet(s["flow"], s["sp"], L)
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(lp0, hutchinson=True, logphi=logphi, logjacdet=logjac)
+    loss = cg.make_loss(log_prob, logpsi, lgl, kappa, G, L, rs, Vconst, beta)
+    fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(lp0), 1e-3, 1e-3)
+    params = s["flow"].unravel(s["theta"], dim)
+    eng = s["flow"].engine(n, dim, s["sp"])
+    res = []
+    for x in (s["x"], DeviceArray.from_numpy(eng, s["x"])):
+        obs, closs, qloss = loss(None, params, s["sidx"], x, v)
+        g, sc = qloss.grad(params, as_pytree=False, reduce=True)
+        cf, qf, qm = fishers_fn(None, params, s["sidx"], x)
+        qf_h = np.asarray(qf).copy()
+        (_, upd), _ = opt.update((None, s["flow"].unravel(g - obs["E_mean"] * sc, dim)), None, (cf, qf, qm))
+        res.append((obs, g, sc, qf_h, qm, s["flow"].ravel(upd, dim)))
+    for a, b in zip(res[0], res[1]):
+        if isinstance(a, dict):
+            assert a == b
+        else:
+            assert np.array_equal(a, b)
+    # the solve left the Fisher matrix intact, and matches LAPACK
+    P = s["theta"].size
+    qf_h, qm = res[0][3], res[0][4]
+    ref = np.linalg.solve(qf_h - np.outer(qm.real, qm.real) - np.outer(qm.imag, qm.imag) + 1e-3 * np.eye(P), res[0][1] - res[0][0]["E_mean"] * res[0][2])
+    gn = float(np.dot(res[0][1] - res[0][0]["E_mean"] * res[0][2], ref))
+    ref *= -min(np.sqrt(1e-3 / gn), 1.0)
+    assert np.abs(res[0][5] - ref).max() < 1e-7 * np.abs(ref).max()
+    # accumulation over two steps on the device (main.py:285-305)
+    from coulombgas_amd.driver import make_update
+    seen = {}
+    spy = cg.sr.GradientTransformation(lambda p: None, lambda gr, st, params=None: (seen.setdefault("fish", params), ((None, s["flow"].unravel(np.zeros(P), dim)), st))[1])
+    update = make_update(loss, spy, 2, fishers_fn)
+    xs = [DeviceArray.from_numpy(eng, s["x"]), DeviceArray.from_numpy(eng, walkers(rng, B, n, dim, L))]
+    Fs = []
+    for xd in xs:
+        Fs.append(np.asarray(fishers_fn(None, params, s["sidx"], xd)[1]).copy())
+    acc = update.new_acc()
+    for a, xd in enumerate(xs):
+        _, _, _, acc = update(None, params, None, s["sidx"], xd, v, acc, a == 1)
+    assert np.abs(np.asarray(seen["fish"][1]) - 0.5 * (Fs[0] + Fs[1])).max() < 1e-15 * np.abs(Fs[0]).max()
+
+
+def test_grad_laplacian_n57_all_memory_placements():
+    """BASELINE config 5 size (n = 57, Emax = 49): cg_grad_laplacian, cg_param_vjp, cg_ewald and the scores on shipped walkers and
+    parameters; Hutchinson and Hutchinson-split against the golden vectors (tests/test_gpu_golden.py) and, here, the two
+    modes against each other through their common gradient, plus the VJP against the resident-score path."""
+    from coulombgas_amd.engine import Engine
+    g = np.load(GOLDEN_DIR + "/golden_n57_d2.npz")
+    n, dim, L = int(g["n"]), int(g["dim"]), float(g["L"])
+    fix = np.load(GOLDEN_DIR + "/shipped_n57_rs10.npz")
+    eng = Engine(n, dim, 2, 16, 16, L, g["sp_indices"])
+    eng.set_params(g["theta"])
+    B = 24
+    rng = np.random.default_rng(57)
+    x = fix["x"][:B]; sidx = state_indices(rng, B, n, g["sp_indices"].shape[0]); v = rng.standard_normal(x.shape)
+    g1, l1 = eng.grad_laplacian(x, sidx, 1, v)
+    g2, l2 = eng.grad_laplacian(x, sidx, 2, v)
+    assert np.isfinite(l1).all() and np.isfinite(l2).all() and np.array_equal(g1, g2)
+    w1, w2 = rng.standard_normal(B), rng.standard_normal(B)
+    ga = eng.param_vjp(x, sidx, w1, w2, use_scores=False)
+    gb = eng.param_vjp(x, sidx, w1, w2)
+    assert np.abs(ga - gb).max() < 1e-9 * np.abs(ga).max()
+    # Ewald sum at n = 57 (1596 pairs x 708 G in the reference's pair form) against the C oracle's pair-form restatement
+    import ctypes as C
+    from coulombgas_amd.build import build_oracle
+    olib = C.CDLL(build_oracle())
+    eng.set_ewald(10, g["G"], 10.0)
+    V = eng.ewald(x)
+    Vr = np.zeros(B)
+    Gl = np.ascontiguousarray(g["G"], dtype=np.int64); xc = np.ascontiguousarray(x)
+    olib.cgo_ewald(n, dim, C.c_double(L), C.c_double(10.0), C.c_double(10.0), Gl.ctypes.data_as(C.c_void_p), Gl.shape[0],
+                   xc.ctypes.data_as(C.c_void_p), B, Vr.ctypes.data_as(C.c_void_p))
+    assert np.abs(V - Vr).max() < 1e-10 * np.abs(Vr).max()
+    eng.close()

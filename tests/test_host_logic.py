@@ -208,6 +208,65 @@ def test_training_loop_runs_and_logs(monkeypatch):
     assert not np.array_equal(flow.ravel(pf, dim), flow.ravel(p0, dim))
 
 
+def test_update_averages_fishers_over_accumulation_steps():
+    """main.py:285-305: the Fisher matrices handed to the optimizer are the MEAN over the accumulation steps.  fishers_fn
+    returns an engine-owned buffer that the next accumulation step overwrites (as the GPU engine's output buffers are): the
+    accumulator must copy on the first step instead of aliasing it (round-1 bug: F_2 instead of (F_1 + F_2) / 2)."""
+    from coulombgas_amd.driver import make_update
+    P = 5
+    rng = np.random.default_rng(0)
+    mats = [rng.standard_normal((P, P)) for _ in range(2)]
+    means = [rng.standard_normal(P) + 1j * rng.standard_normal(P) for _ in range(2)]
+    out_buffer, calls, seen = np.zeros((P, P)), [0], {}
+
+    def fishers_fn(params_van, params_flow, state_indices, x):
+        k = calls[0]; calls[0] += 1
+        out_buffer[...] = mats[k]                      # the same array object every call
+        return None, out_buffer, means[k]
+
+    def observable_and_lossfn(params_van, params_flow, state_indices, x, key):
+        q = lambda p: (0.0, 0.0)
+        q.grad = lambda p, reduce=False: ({"w": np.ones(P)}, {"w": np.zeros(P)})
+        return {k: 1.0 for k in cg.driver.DATA_KEYS}, None, q
+
+    def opt_update(grads, state, params=None):
+        seen["fish"] = params
+        return (None, {"w": np.zeros(P)}), state
+    opt = cg.sr.GradientTransformation(lambda p: None, opt_update)
+    update = make_update(observable_and_lossfn, opt, 2, fishers_fn)
+    acc = update.new_acc()
+    pf = {"w": np.zeros(P)}
+    for a in range(2):
+        _, pf, _, acc = update(None, pf, None, None, np.zeros((3, 2, 2)), None, acc, a == 1)
+    cf, qf, qm = seen["fish"]
+    assert cf is None
+    assert np.allclose(qf, 0.5 * (mats[0] + mats[1]), rtol=0, atol=1e-15)
+    assert np.allclose(qm, 0.5 * (means[0] + means[1]), rtol=0, atol=1e-15)
+
+
+def test_train_checkpoint_and_resume(monkeypatch, tmp_path):
+    """main.py:217-223, 374-381: train() writes {"keys", "x", "params_van", "params_flow", "opt_state"} with the reference's
+    leading device axis on x, and a run resumed from that file continues with the saved walkers, parameters and Adam moments."""
+    emul_engine.install(monkeypatch)
+    n, dim, L = 4, 2, 2.0
+    sp = orbitals(dim)
+    flow = cg.FermiNet(2, 4, 4, L)
+    p0 = flow.init(3, np.zeros((n, dim)))
+    samp = cg.GroundStateSampler(n, sp.shape[0])
+    kw = dict(rs=2.0, beta=1 / (4 * 0.15), batch=8, sampler=samp, log_prob=samp.log_prob, mc_therm=1, mc_steps=3, seed=1,
+              ckpt_path=str(tmp_path), ckpt_every=2)
+    _, pf2, rows2 = cg.train(flow, p0, sp, n, dim, L, epochs=2, optimizer=cg.adam(1e-2), **kw)
+    ck = cg.load_data(cg.ckpt_filename(2, str(tmp_path)))
+    assert set(ck) == {"keys", "x", "params_van", "params_flow", "opt_state"}
+    assert ck["x"].shape == (1, 8, n, dim) and ck["opt_state"]["count"] == 2
+    assert np.array_equal(flow.ravel(ck["params_flow"], dim), flow.ravel(pf2, dim))
+    rows = []
+    _, pf4, rows4 = cg.train(flow, p0, sp, n, dim, L, epochs=4, optimizer=cg.adam(1e-2), epoch_finished=2, log=rows.append, **kw)
+    assert [int(r.split()[0]) for r in rows4] == [3, 4] and rows == rows4
+    assert not np.array_equal(flow.ravel(pf4, dim), flow.ravel(pf2, dim))
+    assert cg.load_data(cg.ckpt_filename(4, str(tmp_path)))["opt_state"]["count"] == 4
+
+
 def test_checkpoint_interop(tmp_path):
     """src/checkpoint.py mirror: jax-pickled pytrees (main.py:374-381) load as numpy without jax (the array
     reconstructor is mapped to numpy, optimizer-state classes to stubs); save_data round-trips; data.txt columns."""

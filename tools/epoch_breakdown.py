@@ -5,10 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import coulombgas_amd as cg
 from coulombgas_amd import sr as SR
-from tests.common import orbitals, box_length
+from coulombgas_amd.synthetic import orbitals, box_length
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-L = box_length(n, 2); sp = orbitals(2, 25); rs = 10.0
+L = box_length(n, 2); sp = orbitals(2, {13: 25, 29: 25, 57: 49}.get(n, 25)); rs = 10.0
 flow = cg.FermiNet(2, 16, 16, L); p0 = flow.init(1, np.zeros((n, 2)))
 samp = cg.GroundStateSampler(n, sp.shape[0])
 G = cg.kpoints(2, 15); Vconst = n * rs / L * cg.Madelung(2, 10, G)
@@ -17,6 +17,9 @@ logpsi, lgl = cg.make_logpsi_grad_laplacian(lp0, hutchinson=True, logphi=logphi,
 loss = cg.make_loss(samp.log_prob, logpsi, lgl, 10, G, L, rs, Vconst, 1 / 0.6)
 fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(lp0), 1e-3, 1e-3)
 x = np.random.default_rng(0).uniform(0, L, (B, n, 2)); key = np.random.SeedSequence(1)
+if "--host-arrays" not in sys.argv:          # default: the walkers live in HBM (DeviceArray), as in coulombgas_amd.train
+    from coulombgas_amd.engine import DeviceArray
+    x = DeviceArray.from_numpy(flow.engine(n, 2, sp), x)
 T = {}
 def tm(name, fn):
     t0 = time.perf_counter(); r = fn(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0; return r
@@ -24,10 +27,10 @@ for ep in range(4):
     if ep == 1: T.clear()
     key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, None, logp, x, p0, 50, 0.1, L))
     data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(None, p0, sidx, x, key))
-    g, s = tm("quantum grad (2 VJP)", lambda: qloss.grad(p0))
+    g, s = tm("quantum grad (scores + VJP)", lambda: qloss.grad(p0, reduce=True))
     f = tm("fishers_fn", lambda: fishers_fn(None, p0, sidx, x))
     gf = {k: {l: g[k][l] - data["E_mean"] * s[k][l] for l in g[k]} for k in g}
-    (uv, uf), _ = tm("SR solve+clip (host)", lambda: opt.update((None, gf), None, f))
+    (uv, uf), _ = tm("SR solve+clip", lambda: opt.update((None, gf), None, f))
     p0 = tm("apply", lambda: cg.apply_updates(p0, uf))
 for k, v in T.items():
     print("%-30s %7.1f ms" % (k, v / 3 * 1e3))

@@ -4,7 +4,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import coulombgas_amd as cg
-from tests.common import orbitals, box_length
+from coulombgas_amd.synthetic import orbitals, box_length
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 L = box_length(n, 2); sp = orbitals(2, 25)
