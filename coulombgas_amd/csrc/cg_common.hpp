@@ -37,8 +37,17 @@ struct CgBlk {
 // consecutive stamps to a per-phase device counter (CG_STAMP(k) ends phase k and starts phase k+1).  Compiles to
 // nothing in the product build.
 #if defined(CG_STAMPS) && defined(__HIPCC__)
-__device__ unsigned long long cg_stamp_acc[64];
+static __device__ unsigned long long cg_stamp_acc[64];   // one copy per translation unit: see CG_STAMP_READER
 __shared__ unsigned long long cg_stamp_lds[32];       // per-workgroup accumulation (no global contention)
+// defines `int NAME(cg_ctx*, unsigned long long* out64, int clear)`: read (and clear) the counters of THIS translation unit
+#define CG_STAMP_READER(NAME)                                                                                      \
+    extern "C" int NAME(cg_ctx* c, unsigned long long* out64, int clear) {                                         \
+        if (!c || !out64) return CG_ERR_ARG;                                                                       \
+        CG_HIP(c, hipStreamSynchronize(c->stream));                                                                \
+        CG_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(cg_stamp_acc), sizeof(unsigned long long) * 64));          \
+        if (clear) { unsigned long long z[64] = {0}; CG_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(cg_stamp_acc), z, sizeof(z))); } \
+        return CG_OK;                                                                                              \
+    }
 static __device__ __forceinline__ void cg_stamp_at(int end_k, int start_k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const unsigned long long t = __builtin_readcyclecounter();
@@ -219,6 +228,17 @@ CG_DEVI double cg_log_12(double w) {
     p = fma(p, r, 1.0);
     const double l = fma(p, r, lc);
     return two ? 0.693147180559945309417232121458 : l;
+}
+// log(w) for w in [1, 2^1000): exponent split off, mantissa through the [1, 2) table routine
+CG_DEVI double cg_log_ge1(double w) {
+#if defined(__HIPCC__)
+    const int hi = __double2hiint(w);
+    const int ex = (hi >> 20) - 1023;
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(w));
+#else
+    int ex; double m = frexp(w, &ex); m *= 2.0; ex -= 1;
+#endif
+    return fma((double)ex, 0.693147180559945309417232121458, cg_log_12(m));
 }
 CG_DEVI double softplus_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));

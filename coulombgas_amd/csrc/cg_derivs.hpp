@@ -91,8 +91,13 @@ struct CgDerivs {
         double* sc = inv_lds ? fast + (da_fast ? (size_t)o.total : 0) : nullptr;
         for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
         b.sync();
-        F::primal(b, th, (const double*)x, n, L, da, o);
-        F::jacobian(b, th, n, L, da, o);
+        const typename F::WFrag* wf = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typename F::WFrag wfrag;
+        if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
+#endif
+        F::primal(b, th, (const double*)x, n, L, da, o, wf);
+        F::jacobian(b, th, n, L, da, o, wf);
         // with the arena in LDS its J slot (dead after the set-up) is inverted in place
         double* Jc = da_fast ? da + o.J : (inv_lds ? sc : ws + w.Jc);
         if (inv_lds && !da_fast) sc += NN;
@@ -100,17 +105,38 @@ struct CgDerivs {
         double* Dc = inv_lds ? sc + NN : ws + w.Dc;
         double* Dinv = inv_lds ? sc + NN + nn2 : ws + w.Dinv;
         int* perm = inv_lds ? (int*)(sc + NN + 2 * nn2) : (int*)(ws + w.perm);
-        if (!da_fast) {
-            for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+        bool inverted = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (inv_lds && N <= 32 && n <= 16 && nn2 >= 128 && b.nthr >= 128) {
+            // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (cg_linalg.hpp); scratch: Dc
+            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            const int wave = b.tid >> 6;
+            if (wave == 0) {
+                if (N == 26) cg_wave_inverse_real<26>(da + o.J, N, N, Jinv, N, Dc);
+                else cg_wave_inverse_real<32>(da + o.J, N, N, Jinv, N, Dc);
+            } else if (wave == 1) {
+                if (n == 13) cg_wave_inverse_complex<13>(da + o.Dm, n, n, Dinv, n, Dc + 64);
+                else cg_wave_inverse_complex<16>(da + o.Dm, n, n, Dinv, n, Dc + 64);
+            }
             b.sync();
+            for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
+            b.sync();
+            inverted = true;
         }
-        (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-        F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
-        for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
-        if (inv_lds) for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
-        b.sync();
-        double la, ar;
-        cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+#endif
+        if (!inverted) {
+            if (!da_fast) {
+                for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+                b.sync();
+            }
+            (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+            if (inv_lds) for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
+            b.sync();
+            double la, ar;
+            cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+        }
         const double* Dm = da + o.Dm;
         double* Ta = ws + w.Ta; double* Kd = ws + w.Kd; double* gz = ws + w.gz;
         // g_ia = T^a_ii = sum_j D_ij (i k_j^a) Dinv_ji

@@ -119,6 +119,7 @@ struct CgFast {
     struct WFrag {
         const double* th;
         double tw[P + 1];  // two-particle layer column h = lane & 15: bias, then P weights  (pair-primal pass)
+        bool inline_libm;  // true: keep sincos inline (derivative kernels: see CG_OUTLINE in cg_common.hpp)
     };
     struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
     struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
@@ -128,7 +129,7 @@ struct CgFast {
     static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w) { w.th = th; }
+    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; }
     static __device__ __forceinline__ void load_pair_cols(const double* __restrict__ th_in, WFrag& w) {
         const double* th = th_in;
         asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
@@ -295,18 +296,26 @@ struct CgFast {
                     for (int a = 0; a < D; ++a) u += w.tw[1 + a] * pf[a] + w.tw[1 + D + a] * pf[D + a];
                     return u;
                 };
+                // sum_j softplus(u_j) = sum_j max(u_j, 0) + log prod_j (1 + e^-|u_j|): the factors lie in [1, 2], so the
+                // product of a block of <= 16 cannot overflow and ONE logarithm per block replaces one per pair (the
+                // logarithm is ~40 % of a softplus); two independent exp chains per trip hide the LDS round trips
+                double pra = 1.0, prb = 1.0;
                 int jj = 0;
                 for (; jj + 1 < jn; jj += 2) {
                     const double* pa = row + jj * PFS; const double* pb = pa + PFS;
                     const double ua = uof(pa), ub = uof(pb);
                     rawd += pa[2 * D] + pb[2 * D];
-                    acc += softplus_only(ua) + softplus_only(ub);
+                    acc += fmax(ua, 0.0) + fmax(ub, 0.0);
+                    pra *= 1.0 + cg_exp_nonpos(-fabs(ua)); prb *= 1.0 + cg_exp_nonpos(-fabs(ub));
                 }
                 if (jj < jn) {
                     const double* pa = row + jj * PFS;
+                    const double ua = uof(pa);
                     rawd += pa[2 * D];
-                    acc += softplus_only(uof(pa));
+                    acc += fmax(ua, 0.0);
+                    pra *= 1.0 + cg_exp_nonpos(-fabs(ua));
                 }
+                acc += cg_log_ge1(pra * prb);
                 asm volatile("" ::: "memory");             // the next block's stores stay behind these reads
             }
             if (rowok) {
@@ -650,7 +659,7 @@ struct CgFast {
                *z = lds + o.z;
         const double rn = 1.0 / (double)n;
         for (int e = b.tid; e < n * D; e += b.nthr) {
-            T s, c; cg_sincos(x[e] * (CG_PI / L), s, c, wf != nullptr);    // out of line in the sampler kernels only
+            T s, c; cg_sincos(x[e] * (CG_PI / L), s, c, wf != nullptr && !wf->inline_libm);    // out of line in the sampler kernels only
             sh[e] = s; ch[e] = c;
         }
         b.sync();
@@ -1021,8 +1030,11 @@ struct CgFast {
             // The Slater matrix may share J's LDS (o.Dm == o.J), so it is formed after the real factorisation.
             double* res = (double*)perm;
             half_logdetJ = 0.5 * cg_blocked_lu_logabsdet(b, lds + o.J, n * D, n * D, res);
+            CG_STAMP(12)                               // (diagnostic builds, this branch: 12 = real LU, 13 = Slater matrix, 14 = complex LU)
             slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
+            CG_STAMP(13)
             cg_blocked_lu_logdet_complex(b, lds + o.Dm, n, n, res, la, ar);
+            CG_STAMP(14)
         }
 #else
         {

@@ -421,16 +421,6 @@ int cg_microbench_fp64(cg_ctx* c, int which, double* tflops) {
     return CG_OK;
 }
 
-#if defined(CG_STAMPS)
-/* diagnostic builds only: read (and clear) the per-phase cycle counters of cg_common.hpp */
-int cg_debug_stamps(cg_ctx* c, unsigned long long* out64, int clear) {
-    if (!c || !out64) return CG_ERR_ARG;
-    CG_HIP(c, hipStreamSynchronize(c->stream));
-    CG_HIP(c, hipMemcpyFromSymbol(out64, HIP_SYMBOL(cg_stamp_acc), sizeof(unsigned long long) * 64));
-    if (clear) { unsigned long long z[64] = {0}; CG_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(cg_stamp_acc), z, sizeof(z))); }
-    return CG_OK;
-}
-#endif
 
 /* ---- device-resident optimisation step (src/VMC.py:39-76, main.py:277-289) ---- */
 int cg_local_energy(cg_ctx* c, const double* grad, const double* lap, const double* V, const double* logp_states, int B,

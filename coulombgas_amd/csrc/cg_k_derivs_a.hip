@@ -275,3 +275,7 @@ int cg_quantum_fisher(cg_ctx* c, const double* x, const int32_t* sidx, int B, do
 }
 
 }  // extern "C"
+
+#if defined(CG_STAMPS)
+CG_STAMP_READER(cg_debug_stamps_derivs)      /* diagnostic builds only (tools/stamps*.py): the per-phase cycle counters of this unit's kernels */
+#endif

@@ -115,3 +115,7 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
 }
 
 }  // extern "C"
+
+#if defined(CG_STAMPS)
+CG_STAMP_READER(cg_debug_stamps)      /* diagnostic builds only (tools/stamps*.py): the per-phase cycle counters of this unit's kernels */
+#endif

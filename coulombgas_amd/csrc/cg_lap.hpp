@@ -174,18 +174,42 @@ struct CgLap {
         double* da = mem.a + l.da; double* x = mem.p + l.x;
         for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
         b.sync();
-        F::primal(b, th, (const double*)x, n, L, da, o);
-        F::jacobian(b, th, n, L, da, o);
+        const typename F::WFrag* wf = nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typename F::WFrag wfrag;
+        if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
+#endif
+        F::primal(b, th, (const double*)x, n, L, da, o, wf);
+        F::jacobian(b, th, n, L, da, o, wf);
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
-        int* perm = (int*)(mem.a + l.perm);
-        for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
-        b.sync();
-        (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-        F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
-        for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
-        b.sync();
-        double la, ar;
-        cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+        bool inverted = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (N <= 32 && n <= 16 && b.nthr >= 128 && N * N + 2 * n * n >= 128) {      // (the Jc + Dc slots are the 128-double scratch)
+            // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (no barriers, J and D intact)
+            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            const int wave = b.tid >> 6;
+            if (wave == 0) {
+                if (N == 26) cg_wave_inverse_real<26>(da + o.J, N, N, Jinv, N, Jc);
+                else cg_wave_inverse_real<32>(da + o.J, N, N, Jinv, N, Jc);
+            } else if (wave == 1) {
+                if (n == 13) cg_wave_inverse_complex<13>(da + o.Dm, n, n, Dinv, n, Jc + 64);
+                else cg_wave_inverse_complex<16>(da + o.Dm, n, n, Dinv, n, Jc + 64);
+            }
+            b.sync();
+            inverted = true;
+        }
+#endif
+        if (!inverted) {
+            int* perm = (int*)(mem.a + l.perm);
+            for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+            b.sync();
+            (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+            b.sync();
+            double la, ar;
+            cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+        }
         const double* Dm = da + o.Dm;
         double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd; double* gz = mem.p + l.gz;
         for (int e = b.tid; e < D * n * n; e += b.nthr) {            // T^a = D diag(i k^a) D^-1
@@ -782,19 +806,28 @@ struct CgLap {
                                        double* __restrict__ lap /*2*/, double* lds, double* ws, const Lay& l) {
         const int N = n * D;
         const Mem<AL> mem(lds, ws, l);
+        CG_STAMP_START(20)
         setup<AL>(b, th, xg, spk, sidx, n, L, mem, l);
+        CG_STAMP_END(20)
         const bool exact_phi = mode != 1;
         double s_re, s_im, q_re = 0, q_im = 0;
+        CG_STAMP_START(21)
         slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im);      // grad <- J^T g
         b.sync();                                                        // Jhat overlays J, the adjoints overlay C
+        CG_STAMP_END(21)
+        CG_STAMP_START(22)
         reverse_x<AL>(b, th, n, L, mem, l);
         {
             const double* xbar = mem.p + l.xbar;
             for (int e = b.tid; e < N; e += b.nthr) grad[2 * e] += xbar[e];   // same thread wrote grad[2 e] above
         }
+        CG_STAMP_END(22)
+        CG_STAMP_START(23)
         if (exact_phi) forward_laplacian<AL>(b, th, n, L, mem, l, q_re, q_im);
         double tot[4] = {s_re + q_re, s_im + q_im, 0.0, 0.0};
         b.sync();                                    // the jet arena overlays the primal arena
+        CG_STAMP_END(23)
+        CG_STAMP_START(24)
         if (mode == 0) {
             for (int dir = 0; dir < N; ++dir) {
                 double r[4];
@@ -807,6 +840,7 @@ struct CgLap {
             jet_part<AL>(b, th, n, L, mem, l, v, 0, mode == 1, r);
             tot[0] += r[0]; tot[1] += r[1]; tot[2] += r[2]; tot[3] += r[3];
         }
+        CG_STAMP_END(24)
         cg_block_sum_n<4>(b, tot, mem.p + l.red);
         if (b.tid == 0) { lap[0] = tot[0] + 0.5 * (tot[2] - tot[3]); lap[1] = tot[1]; }
         b.sync();

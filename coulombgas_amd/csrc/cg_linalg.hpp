@@ -436,6 +436,163 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
+// Wave-level INVERSES (gfx950), same lane layouts as the wave-level LUs above: Gauss-Jordan on [A | I] held in registers,
+// one wave, no barriers.  Rows never move: the row that serves as the pivot of step k ends up holding row k of A^-1 and
+// stores it there.  The pivot row goes through an LDS scratch (A part right of the pivot column + the whole I part),
+// every lane reads it back (LDS executes one wave's accesses in order).  A is left intact.  Used by the set-up of the
+// derivative kernels (J^-1 and D^-1 of one walker concurrently on two waves) instead of the workgroup-wide
+// Gauss-Jordan with four barriers per column.
+//   real    : N <= NMAX <= 32, lane = 2 r + c, columns j = 2 m + c;   scr: 4 * (NMAX/2 + 1) doubles of LDS
+//   complex : N <= NMAX <= 16, lane = 4 r + c, columns j = 4 m + c;   scr: 4 * NMAX + 16 doubles of LDS
+// ------------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int NMAX>
+__device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int lda, double* Ainv, int ldi, double* scr) {
+    constexpr int MH = NMAX / 2, MHP = (MH + 1) & ~1;
+    const int lane = threadIdx.x & 63, r = lane >> 1, c = lane & 1;
+    double a[MH], bi[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) {
+        const int j = 2 * m + c;
+        a[m] = (r < N && j < N) ? A[r * lda + j] : 0.0;
+        bi[m] = (j == r) ? 1.0 : 0.0;
+    }
+    bool done = r >= N;
+    unsigned long long donemask = N >= 32 ? 0ull : ~0ull << (2 * N);
+    int myk = -1;
+    double* mineA = scr + c * MHP;
+    double* mineB = scr + 2 * MHP + c * MHP;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < N) {
+            const int ck = k & 1, mk = k >> 1;
+            const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);
+            int p = (int)__builtin_ctzll(~donemask);
+            double piv = cg_readlane_f64(ak, p);
+            if (__ballot(!done && fabs(ak) * 0.25 > fabs(piv))) {      // threshold pivoting (see cg_wave_lu2_logabsdet)
+                const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(fabs(ak)) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !done);
+                p = mask ? (int)__builtin_ctzll(mask) : p;
+                piv = cg_readlane_f64(ak, p);
+            }
+            const double rinv = cg_fast_rcp(piv);
+            const bool isp = r == (p >> 1);
+            const double l = isp ? 0.0 : ak * rinv;          // Jordan step: every other row, finished ones included
+            const int m0 = ck ? mk + 1 : mk;
+            if (isp) {
+#pragma unroll
+                for (int m = m0; m < MH; ++m) mineA[m] = a[m];
+#pragma unroll
+                for (int m = 0; m < MH; ++m) mineB[m] = bi[m];
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int m = m0; m < MH; ++m) a[m] = fma(-l, mineA[m], a[m]);
+#pragma unroll
+            for (int m = 0; m < MH; ++m) bi[m] = fma(-l, mineB[m], bi[m]);
+            asm volatile("" ::: "memory");
+            if (isp) {                                       // the pivot row itself: scaled, it is row k of [I | A^-1] now
+#pragma unroll
+                for (int m = m0; m < MH; ++m) a[m] *= rinv;
+#pragma unroll
+                for (int m = 0; m < MH; ++m) bi[m] *= rinv;
+                myk = k;
+            }
+            done = done || isp;
+            donemask |= 3ull << (p & ~1);
+        }
+    }
+    if (myk >= 0) {
+#pragma unroll
+        for (int m = 0; m < MH; ++m) { const int j = 2 * m + c; if (j < N) Ainv[myk * ldi + j] = bi[m]; }
+    }
+}
+
+template <int NMAX>
+__device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, int lda, double* Ainv, int ldi, double* scr) {
+    constexpr int MQ = (NMAX + 3) / 4;
+    const int lane = threadIdx.x & 63, r = lane >> 2, c = lane & 3;
+    double ar[MQ], ai[MQ], br[MQ], bim[MQ];
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        const int j = 4 * m + c;
+        const bool ok = r < N && j < N;
+        ar[m] = ok ? A[2 * (r * lda + j)] : 0.0;
+        ai[m] = ok ? A[2 * (r * lda + j) + 1] : 0.0;
+        br[m] = (j == r) ? 1.0 : 0.0; bim[m] = 0.0;
+    }
+    bool done = r >= N;
+    unsigned long long donemask = N >= 16 ? 0ull : ~0ull << (4 * N);
+    int myk = -1;
+    double* mineA = scr + 2 * c;                        // complex element j = 4 m + c at scr[2 j]
+    double* mineB = scr + 2 * (4 * MQ) + 2 * c;
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        if (k < N) {
+            const int ck = k & 3, mk = k >> 2;
+            double akr, aki;
+            if (ck == 0) { akr = cg_dpp_f64<0x00>(ar[mk]); aki = cg_dpp_f64<0x00>(ai[mk]); }
+            else if (ck == 1) { akr = cg_dpp_f64<0x55>(ar[mk]); aki = cg_dpp_f64<0x55>(ai[mk]); }
+            else if (ck == 2) { akr = cg_dpp_f64<0xAA>(ar[mk]); aki = cg_dpp_f64<0xAA>(ai[mk]); }
+            else { akr = cg_dpp_f64<0xFF>(ar[mk]); aki = cg_dpp_f64<0xFF>(ai[mk]); }
+            const double m2 = akr * akr + aki * aki;
+            int p = (int)__builtin_ctzll(~donemask);
+            if (__ballot(!done && m2 * 0.0625 > cg_readlane_f64(m2, p))) {
+                const unsigned key = done ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !done);
+                p = mask ? (int)__builtin_ctzll(mask) : p;
+            }
+            const bool isp = r == (p >> 2);
+            const CgCplx piv = {cg_readlane_f64(akr, p), cg_readlane_f64(aki, p)};
+            const double rd = cg_fast_rcp(piv.re * piv.re + piv.im * piv.im);
+            const CgCplx rinv = {piv.re * rd, -piv.im * rd};
+            CgCplx l = cmul({akr, aki}, rinv);
+            if (isp) { l.re = 0.0; l.im = 0.0; }
+            const int m0 = ck == 3 ? mk + 1 : mk;
+            if (isp) {
+#pragma unroll
+                for (int m = m0; m < MQ; ++m) { mineA[8 * m] = ar[m]; mineA[8 * m + 1] = ai[m]; }
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) { mineB[8 * m] = br[m]; mineB[8 * m + 1] = bim[m]; }
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int m = m0; m < MQ; ++m) {
+                const double pr = mineA[8 * m], pi = mineA[8 * m + 1];
+                ar[m] = fma(-l.re, pr, fma(l.im, pi, ar[m]));
+                ai[m] = fma(-l.re, pi, fma(-l.im, pr, ai[m]));
+            }
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) {
+                const double pr = mineB[8 * m], pi = mineB[8 * m + 1];
+                br[m] = fma(-l.re, pr, fma(l.im, pi, br[m]));
+                bim[m] = fma(-l.re, pi, fma(-l.im, pr, bim[m]));
+            }
+            asm volatile("" ::: "memory");
+            if (isp) {
+#pragma unroll
+                for (int m = m0; m < MQ; ++m) { const CgCplx v = cmul({ar[m], ai[m]}, rinv); ar[m] = v.re; ai[m] = v.im; }
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) { const CgCplx v = cmul({br[m], bim[m]}, rinv); br[m] = v.re; bim[m] = v.im; }
+                myk = k;
+            }
+            done = done || isp;
+            donemask |= 15ull << (p & ~3);
+        }
+    }
+    if (myk >= 0) {
+#pragma unroll
+        for (int m = 0; m < MQ; ++m) {
+            const int j = 4 * m + c;
+            if (j < N) { Ainv[2 * (myk * ldi + j)] = br[m]; Ainv[2 * (myk * ldi + j) + 1] = bim[m]; }
+        }
+    }
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
 // Workgroup-wide BLOCKED LU on a matrix in LDS (gfx950): sizes beyond the register LUs (N > 32; n = 29, 57, ...).
 // Right-looking, panel width 4 = the K of v_mfma_f64_16x16x4_f64:
 //   panel   (wave 0): partial pivoting on the panel's 4 columns (row swaps applied to whole rows), L21 scaled in place,
@@ -450,7 +607,7 @@ typedef double cg_d4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void cg_wave_lds_fence_b() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // returns log|det A| in every thread; A (N x N, row-major, lda) is destroyed.  res: >= 2 doubles of LDS scratch.
-__device__ __forceinline__ double cg_blocked_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, double* res) {
+__device__ __forceinline__ double cg_blocked_lu_logabsdet_lds(const CgBlk& b, double* A, int N, int lda, double* res) {
     const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
     const int col = lane & 15, kq = lane >> 4;
     CgScaledProd prod; prod.init();                       // meaningful in wave 0
@@ -522,8 +679,8 @@ __device__ __forceinline__ double cg_blocked_lu_logabsdet(const CgBlk& b, double
 
 // complex version: A interleaved (re,im), lda in complex elements.  Returns log|det| and arg(det) (with the sign of
 // the row permutation) in every thread.  res: >= 2 doubles of LDS scratch.
-__device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, double* res,
-                                                            double& logabs, double& arg) {
+__device__ __forceinline__ void cg_blocked_lu_logdet_complex_lds(const CgBlk& b, double* A, int N, int lda, double* res,
+                                                                double& logabs, double& arg) {
     const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
     const int col = lane & 15, kq = lane >> 4;
     CgCplx pm = {1.0, 0.0}; int pe = 0;                   // meaningful in wave 0
@@ -608,6 +765,375 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, dou
                     const int rr = r0 + kq + 4 * r;
                     if (rr < N && bc < N) { A[2 * (rr * lda + bc)] = cr[r]; A[2 * (rr * lda + bc) + 1] = ci[r]; }
                 }
+            }
+        }
+        b.sync();
+    }
+    if (b.tid == 0) {
+        res[0] = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+        res[1] = cg_atan2_ool(pm.im, pm.re);
+    }
+    b.sync();
+    logabs = res[0]; arg = res[1];
+    b.sync();
+}
+
+// ---- register-resident panels + look-ahead --------------------------------------------------------------------------
+// Blocked right-looking LU with PW = 8 columns per panel.
+//   panel   : factored by wave 0 IN REGISTERS (lane = row, up to two rows per lane for the real matrix: N <= 128; one
+//             complex row per lane: N <= 64): pivot search by DPP max, the pivot row's entries broadcast by readlane, the row
+//             exchange inside the panel done on registers; LDS is touched twice (load, store) instead of ~15 dependent
+//             round trips per column.
+//   deferred exchanges + U12 : the exchange of the REST of the two rows is deferred: the pivots go to LDS and the owner of a
+//             column applies the exchanges to it and forward-substitutes its U12 entries (column-local); columns left of
+//             the panel are never needed again (only the determinant is wanted).
+//   trailing : A22 -= L21 U12 on 16 x 16 MFMA tiles with K = PW, two tiles per trip.
+//   look-ahead: the sequential pivot chain of the panels is the critical path (one wave, ~1 k cycles per column).  While
+//             the other waves apply panel k to the columns right of panel k+1 (each wave owns whole 16-column blocks:
+//             exchanges + U12 for its columns, then their row tiles -- no synchronisation between the waves), wave 0
+//             applies panel k to the columns of panel k+1 only and factors panel k+1.  ONE workgroup barrier per panel
+//             (the LDS version: two per 4 columns with all other waves idle during the panel).
+// res: >= 12 doubles of LDS (result + double-buffered pivots).
+#define CG_LU_PW 8
+struct CgLuPanelReal {
+    // factor panel starting at column k0 (kb columns) -> L in place, pivots to pv; returns through `prod`
+    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgScaledProd& prod) {
+        constexpr int PW = CG_LU_PW;
+        const int r0 = k0 + lane, r1 = r0 + 64;
+        double a0[PW], a1[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            a0[j] = (r0 < N && j < kb) ? A[r0 * lda + k0 + j] : 0.0;
+            a1[j] = (r1 < N && j < kb) ? A[r1 * lda + k0 + j] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (j < kb) {
+                const int k = k0 + j;
+                // threshold pivoting (as in the wave-level LUs): row k serves unless some candidate is more than 4x larger
+                // (growth bounded by 5 per step); only then the full search and the row exchange run.  For J = I + small
+                // the short path is the only one taken; it removes the DPP max chain from the sequential pivot chain.
+                const double c0v = (r0 >= k && r0 < N) ? fabs(a0[j]) : 0.0, c1v = (r1 < N) ? fabs(a1[j]) : 0.0;
+                const double akk = cg_readlane_f64(c0v, j);
+                int p = k;
+                if (__ballot(fmax(c0v, c1v) * 0.25 > akk)) {
+                    const unsigned key0 = (r0 >= k && r0 < N) ? (unsigned)(__double_as_longlong(c0v) >> 32) + 1u : 0u;
+                    const unsigned key1 = (r1 < N) ? (unsigned)(__double_as_longlong(c1v) >> 32) + 1u : 0u;
+                    const unsigned key = key1 > key0 ? key1 : key0;
+                    const int bi = key1 > key0 ? r1 : r0;
+                    const unsigned mx = cg_wave_max_u32(key);
+                    const unsigned long long mask = __ballot(key == mx);
+                    p = __builtin_amdgcn_readlane(bi, (int)__builtin_ctzll(mask));
+                }
+                const int lp = (p - k0) & 63, sp = (p - k0) >> 6;         // wave-uniform
+                double rp[PW];
+#pragma unroll
+                for (int jj = 0; jj < PW; ++jj) rp[jj] = cg_readlane_f64(sp ? a1[jj] : a0[jj], lp);
+                if (p != k) {                                             // exchange rows k and p inside the panel
+#pragma unroll
+                    for (int jj = 0; jj < PW; ++jj) {
+                        const double rk = cg_readlane_f64(a0[jj], j);
+                        if (lane == j) a0[jj] = rp[jj];
+                        if (lane == lp) { if (sp) a1[jj] = rk; else a0[jj] = rk; }
+                    }
+                }
+                if (lane == 0) pv[j] = p;
+                const double piv = rp[j];
+                prod.mul(piv);
+                const double rinv = cg_fast_rcp1(piv);                     // (the determinant uses the pivots themselves)
+                if (r0 > k && r0 < N) {
+                    const double l = a0[j] * rinv; a0[j] = l;
+#pragma unroll
+                    for (int jj = j + 1; jj < PW; ++jj) a0[jj] = fma(-l, rp[jj], a0[jj]);
+                }
+                if (r1 < N) {
+                    const double l = a1[j] * rinv; a1[j] = l;
+#pragma unroll
+                    for (int jj = j + 1; jj < PW; ++jj) a1[jj] = fma(-l, rp[jj], a1[jj]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (j < kb) {
+                if (r0 < N) A[r0 * lda + k0 + j] = a0[j];
+                if (r1 < N) A[r1 * lda + k0 + j] = a1[j];
+            }
+        }
+    }
+    // deferred row exchanges of panel (k0, kb, pv) applied to column c, then U12[:, c] = L11^-1 A12[:, c]
+    static __device__ __forceinline__ void column(double* A, int lda, int k0, int kb, const int* pv, int c) {
+        constexpr int PW = CG_LU_PW;
+        double u[PW];
+#pragma unroll
+        for (int r = 0; r < PW; ++r) u[r] = r < kb ? A[(k0 + r) * lda + c] : 0.0;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (j < kb) {
+                const int p = pv[j];
+                if (p != k0 + j) {
+                    if (p < k0 + PW) {
+#pragma unroll
+                        for (int q = j + 1; q < PW; ++q) if (p - k0 == q) { const double t = u[j]; u[j] = u[q]; u[q] = t; }
+                    } else {
+                        const double t = A[p * lda + c]; A[p * lda + c] = u[j]; u[j] = t;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 1; r < PW; ++r)
+            if (r < kb) {
+#pragma unroll
+                for (int q = 0; q < r; ++q) u[r] = fma(-A[(k0 + r) * lda + k0 + q], u[q], u[r]);
+            }
+#pragma unroll
+        for (int r = 0; r < PW; ++r) if (r < kb) A[(k0 + r) * lda + c] = u[r];
+    }
+    // row tiles ti = 0.. of the column block [c0, cend) (cend - c0 <= 16): A22 -= L21 U12 for rows >= m0, two tiles per trip
+    static __device__ __forceinline__ void tiles(double* A, int N, int lda, int k0, int kb, int m0, int c0, int cend, int lane) {
+        constexpr int PW = CG_LU_PW;
+        const int col = lane & 15, kq = lane >> 4;
+        const int rtiles = (N - m0 + 15) >> 4;
+        const int bc = c0 + col;
+        const bool cok = bc < cend;
+        double bv[PW / 4];
+#pragma unroll
+        for (int ks = 0; ks < PW / 4; ++ks) { const int kk = 4 * ks + kq; bv[ks] = (cok && kk < kb) ? A[(k0 + kk) * lda + bc] : 0.0; }
+        for (int t0 = 0; t0 < rtiles; t0 += 2) {
+            cg_d4_t c[2]; double av[2][PW / 4]; int rr0[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r0 = m0 + 16 * (t0 + h);
+                const int ar = r0 + col;
+                rr0[h] = r0 + kq;
+#pragma unroll
+                for (int ks = 0; ks < PW / 4; ++ks) { const int kk = 4 * ks + kq; av[h][ks] = (ar < N && kk < kb) ? -A[ar * lda + k0 + kk] : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int rr = rr0[h] + 4 * r; c[h][r] = (rr < N && cok) ? A[rr * lda + bc] : 0.0; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < PW / 4; ++ks) c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][ks], bv[ks], c[h], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int rr = rr0[h] + 4 * r; if (rr < N && cok) A[rr * lda + bc] = c[h][r]; }
+        }
+    }
+};
+
+__device__ __forceinline__ double cg_blocked_lu_logabsdet(const CgBlk& b, double* A, int N, int lda, double* res) {
+    const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
+    if (N > 128 || nw < 2) return cg_blocked_lu_logabsdet_lds(b, A, N, lda, res);
+    constexpr int PW = CG_LU_PW;
+    int* pivs = (int*)(res + 2);                          // [2][PW]
+    const int npan = (N + PW - 1) / PW;
+    CgScaledProd prod; prod.init();                       // meaningful in wave 0
+    if (wave == 0) CgLuPanelReal::factor(A, N, lda, 0, N < PW ? N : PW, lane, pivs, prod);
+    b.sync();
+    for (int k = 0; k < npan; ++k) {
+        const int k0 = k * PW, kb = N - k0 < PW ? N - k0 : PW, m0 = k0 + kb;
+        const int nb = N - m0 < PW ? N - m0 : PW;          // width of panel k + 1 (0: none)
+        const int* pv = pivs + (k & 1) * PW;
+        if (wave == 0) {
+            if (nb > 0) {                                  // panel k applied to the columns of panel k + 1, then panel k + 1
+                CG_STAMP_START(16)
+                if (lane < nb) CgLuPanelReal::column(A, lda, k0, kb, pv, m0 + lane);
+                asm volatile("" ::: "memory");             // (LDS executes one wave's accesses in order)
+                CG_STAMP(16)
+                CgLuPanelReal::tiles(A, N, lda, k0, kb, m0, m0, m0 + nb, lane);
+                asm volatile("" ::: "memory");
+                CG_STAMP(17)
+                CgLuPanelReal::factor(A, N, lda, m0, nb, lane, pivs + ((k + 1) & 1) * PW, prod);
+                CG_STAMP_END(18)
+            }
+        } else {
+            const int cb0 = m0 + nb;                       // the other waves: whole 16-column blocks right of panel k + 1
+            const int ctiles = (N - cb0 + 15) >> 4;
+            CG_STAMP_START(19)
+            for (int tj = wave - 1; tj < ctiles; tj += nw - 1) {
+                const int c0 = cb0 + 16 * tj, cend = c0 + 16 < N ? c0 + 16 : N;
+                if (lane < 16 && c0 + lane < N) CgLuPanelReal::column(A, lda, k0, kb, pv, c0 + lane);
+                asm volatile("" ::: "memory");
+                CgLuPanelReal::tiles(A, N, lda, k0, kb, m0, c0, cend, lane);
+            }
+            CG_STAMP_END(19)
+        }
+        b.sync();
+    }
+    if (b.tid == 0) res[0] = prod.logabs(true);
+    b.sync();
+    const double v = res[0];
+    b.sync();
+    return v;
+}
+
+struct CgLuPanelCplx {
+    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgCplx& pm, int& pe) {
+        constexpr int PW = CG_LU_PW;
+        const int r0 = k0 + lane;
+        double ar_[PW], ai_[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const bool ok = r0 < N && j < kb;
+            ar_[j] = ok ? A[2 * (r0 * lda + k0 + j)] : 0.0;
+            ai_[j] = ok ? A[2 * (r0 * lda + k0 + j) + 1] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (j < kb) {
+                const int k = k0 + j;
+                // threshold pivoting: row k serves unless some candidate is more than 4x larger in modulus
+                const double m2 = (r0 >= k && r0 < N) ? ar_[j] * ar_[j] + ai_[j] * ai_[j] : 0.0;
+                const double mkk = cg_readlane_f64(m2, j);
+                int lp = j;                                               // lane of the pivot row (one row per lane)
+                if (__ballot(m2 * 0.0625 > mkk)) {
+                    const unsigned key = (r0 >= k && r0 < N) ? (unsigned)(__double_as_longlong(m2) >> 32) + 1u : 0u;
+                    const unsigned mx = cg_wave_max_u32(key);
+                    const unsigned long long mask = __ballot(key == mx);
+                    lp = (int)__builtin_ctzll(mask);
+                }
+                const int p = k0 + lp;
+                double rpr[PW], rpi[PW];
+#pragma unroll
+                for (int jj = 0; jj < PW; ++jj) { rpr[jj] = cg_readlane_f64(ar_[jj], lp); rpi[jj] = cg_readlane_f64(ai_[jj], lp); }
+                if (p != k) {
+#pragma unroll
+                    for (int jj = 0; jj < PW; ++jj) {
+                        const double rkr = cg_readlane_f64(ar_[jj], j), rki = cg_readlane_f64(ai_[jj], j);
+                        if (lane == j) { ar_[jj] = rpr[jj]; ai_[jj] = rpi[jj]; }
+                        if (lane == lp) { ar_[jj] = rkr; ai_[jj] = rki; }
+                    }
+                }
+                if (lane == 0) pv[j] = p;
+                const CgCplx piv = {rpr[j], rpi[j]};
+                pm = cmul(pm, piv);
+                if (p != k) { pm.re = -pm.re; pm.im = -pm.im; }
+                { int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
+                  pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex; }
+                const double rd = cg_fast_rcp1(piv.re * piv.re + piv.im * piv.im);
+                const CgCplx rinv = {piv.re * rd, -piv.im * rd};
+                if (r0 > k && r0 < N) {
+                    const CgCplx l = cmul({ar_[j], ai_[j]}, rinv);
+                    ar_[j] = l.re; ai_[j] = l.im;
+#pragma unroll
+                    for (int jj = j + 1; jj < PW; ++jj) {
+                        const double re = ar_[jj] - (l.re * rpr[jj] - l.im * rpi[jj]), im = ai_[jj] - (l.re * rpi[jj] + l.im * rpr[jj]);
+                        ar_[jj] = re; ai_[jj] = im;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PW; ++j)
+            if (j < kb && r0 < N) { A[2 * (r0 * lda + k0 + j)] = ar_[j]; A[2 * (r0 * lda + k0 + j) + 1] = ai_[j]; }
+    }
+    static __device__ __forceinline__ void column(double* A, int lda, int k0, int kb, const int* pv, int c) {
+        constexpr int PW = CG_LU_PW;
+        CgCplx u[PW];
+#pragma unroll
+        for (int r = 0; r < PW; ++r) u[r] = r < kb ? CgCplx{A[2 * ((k0 + r) * lda + c)], A[2 * ((k0 + r) * lda + c) + 1]} : CgCplx{0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (j < kb) {
+                const int p = pv[j];
+                if (p != k0 + j) {
+                    if (p < k0 + PW) {
+#pragma unroll
+                        for (int q = j + 1; q < PW; ++q) if (p - k0 == q) { const CgCplx t = u[j]; u[j] = u[q]; u[q] = t; }
+                    } else {
+                        double* y = A + 2 * (p * lda + c);
+                        const CgCplx t = {y[0], y[1]}; y[0] = u[j].re; y[1] = u[j].im; u[j] = t;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 1; r < PW; ++r)
+            if (r < kb) {
+#pragma unroll
+                for (int q = 0; q < r; ++q) {
+                    const CgCplx l = {A[2 * ((k0 + r) * lda + k0 + q)], A[2 * ((k0 + r) * lda + k0 + q) + 1]};
+                    u[r] = csub(u[r], cmul(l, u[q]));
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < PW; ++r) if (r < kb) { A[2 * ((k0 + r) * lda + c)] = u[r].re; A[2 * ((k0 + r) * lda + c) + 1] = u[r].im; }
+    }
+    static __device__ __forceinline__ void tiles(double* A, int N, int lda, int k0, int kb, int m0, int c0, int cend, int lane) {
+        constexpr int PW = CG_LU_PW;
+        const int col = lane & 15, kq = lane >> 4;
+        const int rtiles = (N - m0 + 15) >> 4;
+        const int bc = c0 + col;
+        const bool cok = bc < cend;
+        double b_re[PW / 4], b_im[PW / 4];
+#pragma unroll
+        for (int ks = 0; ks < PW / 4; ++ks) {
+            const int kk = 4 * ks + kq; const bool bok = cok && kk < kb;
+            b_re[ks] = bok ? A[2 * ((k0 + kk) * lda + bc)] : 0.0; b_im[ks] = bok ? A[2 * ((k0 + kk) * lda + bc) + 1] : 0.0;
+        }
+        for (int ti = 0; ti < rtiles; ++ti) {
+            const int r0 = m0 + 16 * ti, ar = r0 + col;
+            double a_re[PW / 4], a_im[PW / 4];
+#pragma unroll
+            for (int ks = 0; ks < PW / 4; ++ks) {
+                const int kk = 4 * ks + kq; const bool aok = ar < N && kk < kb;
+                a_re[ks] = aok ? A[2 * (ar * lda + k0 + kk)] : 0.0; a_im[ks] = aok ? A[2 * (ar * lda + k0 + kk) + 1] : 0.0;
+            }
+            cg_d4_t cr, ci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + kq + 4 * r; const bool ok = rr < N && cok;
+                cr[r] = ok ? A[2 * (rr * lda + bc)] : 0.0; ci[r] = ok ? A[2 * (rr * lda + bc) + 1] : 0.0;
+            }
+#pragma unroll
+            for (int ks = 0; ks < PW / 4; ++ks) {
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_re[ks], b_re[ks], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_re[ks], b_im[ks], ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im[ks], b_im[ks], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_im[ks], b_re[ks], ci, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + kq + 4 * r;
+                if (rr < N && cok) { A[2 * (rr * lda + bc)] = cr[r]; A[2 * (rr * lda + bc) + 1] = ci[r]; }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, double* A, int N, int lda, double* res,
+                                                            double& logabs, double& arg) {
+    const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
+    if (N > 64 || nw < 2) { cg_blocked_lu_logdet_complex_lds(b, A, N, lda, res, logabs, arg); return; }
+    constexpr int PW = CG_LU_PW;
+    int* pivs = (int*)(res + 2);                          // [2][PW]
+    const int npan = (N + PW - 1) / PW;
+    CgCplx pm = {1.0, 0.0}; int pe = 0;                   // meaningful in wave 0
+    if (wave == 0) CgLuPanelCplx::factor(A, N, lda, 0, N < PW ? N : PW, lane, pivs, pm, pe);
+    b.sync();
+    for (int k = 0; k < npan; ++k) {
+        const int k0 = k * PW, kb = N - k0 < PW ? N - k0 : PW, m0 = k0 + kb;
+        const int nb = N - m0 < PW ? N - m0 : PW;
+        const int* pv = pivs + (k & 1) * PW;
+        if (wave == 0) {
+            if (nb > 0) {
+                if (lane < nb) CgLuPanelCplx::column(A, lda, k0, kb, pv, m0 + lane);
+                asm volatile("" ::: "memory");
+                CgLuPanelCplx::tiles(A, N, lda, k0, kb, m0, m0, m0 + nb, lane);
+                asm volatile("" ::: "memory");
+                CgLuPanelCplx::factor(A, N, lda, m0, nb, lane, pivs + ((k + 1) & 1) * PW, pm, pe);
+            }
+        } else {
+            const int cb0 = m0 + nb;
+            const int ctiles = (N - cb0 + 15) >> 4;
+            for (int tj = wave - 1; tj < ctiles; tj += nw - 1) {
+                const int c0 = cb0 + 16 * tj, cend = c0 + 16 < N ? c0 + 16 : N;
+                if (lane < 16 && c0 + lane < N) CgLuPanelCplx::column(A, lda, k0, kb, pv, c0 + lane);
+                asm volatile("" ::: "memory");
+                CgLuPanelCplx::tiles(A, N, lda, k0, kb, m0, c0, cend, lane);
             }
         }
         b.sync();

@@ -10,7 +10,9 @@ from coulombgas_amd.engine import Engine
 from coulombgas_amd import _lib
 
 NAMES = ["proposal+rng", "sincos", "primal pairs", "primal dense", "wt staging", "factors U,Bm", "G pass", "Up", "B.G",
-         "factors V", "jacobian pairs", "diag blocks", "slater matrix", "real LU", "complex LU", "accept"]
+         "factors V", "jacobian pairs", "diag blocks", "slater matrix", "real LU", "complex LU", "accept",
+         "LU wave0: strip columns", "LU wave0: strip tiles", "LU wave0: panel", "LU other waves: columns+tiles"]
+# (n > 16: 12 = real LU, 13 = Slater matrix, 14 = complex LU; 16-19: inside the real blocked LU, already counted in 12)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 Emax = {13: 25, 29: 25, 57: 49}[n]
@@ -27,8 +29,8 @@ eng.timer_start()
 eng.mcmc_dev(d_x, d_s, B, steps, 0.1, seed=2, walker_offset=0, logp_buf=d_lp)
 ms = eng.timer_stop()
 fn(eng._ctx, buf.ctypes.data, 1)
-cyc = buf.astype(np.int64)[:16].astype(np.float64)
-tot = cyc.sum()
+cyc = buf.astype(np.int64)[:20].astype(np.float64)
+tot = cyc[:16].sum()
 print("n=%d B=%d: kernel %.2f ms (stamped build); cycles per wave per evaluation:" % (n, B, ms))
 for k, nm in enumerate(NAMES):
     print("  %2d %-16s %9.0f  %5.1f %%" % (k, nm, cyc[k] / (B * (steps + 1)), 100 * cyc[k] / tot))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: cycles per phase of the directional passes of k_grad_lap (s_memtime stamps, -DCG_STAMPS build).
+"""Diagnostic: cycles per phase of k_grad_lap2 (s_memtime stamps, -DCG_STAMPS build).
    python -m coulombgas_amd.build --diag cg_stamps -DCG_STAMPS -DCG_ONLY_2_16_16
    COULOMBGAS_HIP_LIB=coulombgas_amd/lib/diag/libcg_stamps.so python tools/stamps_gradlap.py [n] [B] [mode]"""
 import sys, os, ctypes as C
@@ -8,15 +8,15 @@ import numpy as np
 from bench import synthetic
 from coulombgas_amd.engine import Engine
 from coulombgas_amd import _lib
-NAMES = {0: "xj init", 1: "sincos", 2: "pair-primal", 3: "dense layers + z", 4: "(convert) factors U,B,V + G pass", 5: "Up",
-         6: "Jacobian pairs", 7: "diag blocks", 8: "reductions", 20: "setup (per walker)"}
+NAMES = {20: "set-up (primal, J, J^-1, D^-1, T, K)", 21: "Slater part (J^T g, tr J^T H J)", 22: "reverse sweep (xbar)",
+         23: "forward Laplacian", 24: "jet pass(es)"}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 L, sp, theta, sidx, x = synthetic(n, 2, B, {13: 25, 29: 25, 57: 49}[n], 0)
 eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta)
 v = np.random.default_rng(0).standard_normal(x.shape)
-fn = C.CDLL(_lib.LIB_PATH).cg_debug_stamps
+fn = C.CDLL(_lib.LIB_PATH).cg_debug_stamps_derivs
 fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 buf = np.zeros(64, dtype=np.uint64)
 eng.grad_laplacian(x, sidx, mode, v)
