@@ -28,10 +28,23 @@ def synthetic(n, dim, B, Emax, rank):
     return bench_inputs(n, dim, B, Emax, rank)
 
 
+def usable_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box gives a 1-GPU job
+    a share of the host, e.g. cpu.max = 16 CPUs of 256)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 DENSE_AD_FLOPS_PER_WALKER_STEP = {13: 2.7e6, 29: 24e6, 57: 170e6}   # SURVEY 8(d): what XLA / the C port execute (dense jacfwd)
 
 
-def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=15.0, reps=5):
+def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=24.0, reps=5):
     """Times the CPU restatement (oracle/cg_oracle.c: the algorithm the reference executes -- dense forward-mode Jacobian with
     n*d tangents, SIMD over the tangents, two LU log-dets; OpenMP over walkers) on the host cores: BASELINE.md section 3 --
     config 1's shape (B = 128, the full call) and a bounded sample of the timed workload's shape, each the MEDIAN of `reps`
@@ -43,6 +56,7 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=15.0,
     lib.cgo_mcmc.restype = C.c_double
     lib.cgo_num_threads.restype = C.c_int
     p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.cgo_set_num_threads(C.c_int(usable_cores()))     # one OpenMP thread per core this process may use
     cores = lib.cgo_num_threads()
 
     def run(Bs, steps):
@@ -60,8 +74,9 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=15.0,
         ts = sorted(run(Bs, steps) for _ in range(reps))
         return Bs * steps / ts[len(ts) // 2], ts
 
-    t = run(min(2 * cores, x.shape[0]), 2)               # calibration
-    rate = min(2 * cores, x.shape[0]) * 2 / t
+    Bc = min(4 * cores, x.shape[0])
+    run(Bc, 3)                                           # thread team start-up, page faults
+    rate = Bc * 3 / run(Bc, 3)                           # calibration
     per_run = budget_s / (2 * (reps + 1))
     # config 1's shape: B = 128 (the whole call if it fits the budget, otherwise fewer Metropolis steps of it)
     B1 = min(128, x.shape[0]); s1 = int(max(1, min(mc_steps, rate * per_run / B1)))
@@ -87,6 +102,7 @@ def energy_check(eng, n, dim, L, sp, theta, sidx, x, rs=10.0, kappa=10, Gmax=15,
     import coulombgas_amd as cg
     from oracle import cg_ref as R
     t0 = time.perf_counter()
+    torch.set_num_threads(usable_cores())                 # torch's default (all host cores) thrashes inside a CPU quota
     G = cg.kpoints(dim, Gmax)
     Vconst = n * rs / L * cg.Madelung(dim, kappa, G)
     eng.set_ewald(kappa, G, rs)
@@ -241,7 +257,7 @@ def main():
             cpu = cpu_baseline(n, dim, L, sp, theta, sidx0, x0, args.mc_steps, args.mc_stddev)
             if not args.no_energy_check:
                 big = n > 16                   # the torch oracle is minutes per walker beyond n = 13: fewer walkers there
-                energy = energy_check(eng, n, dim, L, sp, theta, sidx, x_final, n_split=4 if big else 64, n_exact=0 if big else 16)
+                energy = energy_check(eng, n, dim, L, sp, theta, sidx, x_final, n_split=4 if big else 64, n_exact=0 if big else 8)
         out = {"metric": "walker-steps/sec (batch x mcsteps/s), n=%d 2D batch %d" % (n, B), "value": value,
                "unit": "walker-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

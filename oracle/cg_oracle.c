@@ -35,6 +35,15 @@ int cgo_num_threads(void) {
 #endif
 }
 
+/* the container's CPU share may be far below the machine's core count (cgroup quota): the caller sets the team size */
+void cgo_set_num_threads(int t) {
+#ifdef _OPENMP
+    if (t > 0) omp_set_num_threads(t);
+#else
+    (void)t;
+#endif
+}
+
 typedef struct {
     int n, dim, depth, hs, ht, M;
     double L;

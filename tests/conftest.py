@@ -14,3 +14,25 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads_within_cpu_quota():
+    """the oracle (torch.func) defaults to one thread per host core; inside a cgroup CPU quota that only thrashes"""
+    try:
+        import torch
+        torch.set_num_threads(_usable_cores())
+    except ImportError:
+        pass
+    yield
