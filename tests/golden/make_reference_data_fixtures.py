@@ -99,6 +99,15 @@ if __name__ == "__main__":
                 {"data_row_last": np.loadtxt(os.path.join(d, "data.txt"))[-1]})
     d = glob.glob("%s/data/n_29_dim_2_rs_10.0_*" % REF)[0]
     van_fixture(os.path.join(d, "epoch_003000.pkl"), "params_van", "shipped_n29_rs10_van.npz", {})
+    # Transformers of the other two statistical KATs (BASELINE configs 4 and 5) and the pretrained n = 29 model the
+    # production runs start from (epoch-1 rows of data.txt: flow ~ identity)
+    d = glob.glob("%s/data/n_29_dim_2_rs_1.0_*" % REF)[0]
+    van_fixture(os.path.join(d, "epoch_003000.pkl"), "params_van", "shipped_n29_rs1_van.npz", {})
+    d = glob.glob("%s/data/n_57_dim_2_rs_10.0_*" % REF)[0]
+    van_fixture(os.path.join(d, "epoch_005000.pkl"), "params_van", "shipped_n57_rs10_van.npz", {})
+    d = glob.glob("%s/data/freefermion/pretraining/n_29_*/*" % REF)[0]
+    van_fixture(os.path.join(d, "params_van.pkl"), None, "pretrained_van_n29.npz",
+                {"data_row_last": np.loadtxt(os.path.join(d, "data.txt"))[-1]})
     for Emax in (25, 36, 49):
         t = twisted_table(2, Emax, (0.25, 0.25))
         np.save(os.path.join(DATA, "orbitals_dim2_Emax%d.npy" % Emax), t)

@@ -547,21 +547,37 @@ def test_full_size_properties():
     assert np.abs(eng.param_vjp(x, sidx, np.full(B, 1.0 / B), np.zeros(B)) - sm.real).max() < 1e-10 * np.abs(sm).max()
 
 
-def test_shipped_model_reproduces_published_energies():
-    """Statistical end-to-end KAT with the shipped n=29, rs=10 epoch-3000 models (Transformer density matrix + trained flow):
-    host sampler -> GPU Metropolis chains -> GPU local energies reproduce the E and F of the published data.txt row
-    (agreement within ~0.15 %; K and V separately are only loose, App. B6)."""
-    import coulombgas_amd as cg
-    n, dim, rs, Theta = 29, 2, 10.0, 0.15
-    L, beta = box_length(n, dim), 1 / (4 * 0.15)
-    sp = orbitals(2, 25)
-    fix = np.load(GOLDEN_DIR + "/shipped_n29_rs10.npz")
-    z = np.load(GOLDEN_DIR + "/shipped_n29_rs10_van.npz")
+def _load_van(name):
+    z = np.load(GOLDEN_DIR + "/" + name)
     pv = {}
     for k in z.files:
-        m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
-    van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
-    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0])
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    return pv
+
+
+@pytest.mark.parametrize("n,rs,Emax,fixture,van,B,rounds,tol", [
+    (29, 10.0, 25, "shipped_n29_rs10.npz", "shipped_n29_rs10_van.npz", 512, 8, 0.005),
+    (29, 1.0, 25, "shipped_n29_rs1.npz", "shipped_n29_rs1_van.npz", 512, 16, 0.005),      # BASELINE config 4 (rs = 1)
+    # BASELINE config 5 (Emax = 49).  Measured with this build: E -9.50 +- 0.004 vs published -9.5518 (0.53 %), K 1.72 vs 1.555,
+    # V -11.22 vs -11.107, acceptance 0.23 vs 0.257 -- stable over 40 sampling rounds and identical in the oracle (the n = 57
+    # golden vectors pin the HIP path to it at 1e-10): the v1-formulas-vs-shipped-data gap of SURVEY App. B6, larger at n = 57.
+    (57, 10.0, 49, "shipped_n57_rs10.npz", "shipped_n57_rs10_van.npz", 256, 12, 0.01),
+])
+def test_shipped_model_reproduces_published_energies(n, rs, Emax, fixture, van, B, rounds, tol):
+    """Statistical end-to-end KATs with the shipped final models (Transformer density matrix + trained flow) of three
+    production runs: host sampler -> GPU Metropolis chains -> GPU local energies (Hutchinson-split, device-resident step)
+    reproduce the E and F of the last published data.txt row within `tol` (0.5 %; 1 % at n = 57) or 4 standard errors of this
+    sample, whichever is larger (v1 formulas + shipped parameters agree with the published E, F to ~0.15 %; K and V separately are only
+    loose, App. B6).  The published row comes from 8192 walkers."""
+    import coulombgas_amd as cg
+    dim = 2
+    L, beta = box_length(n, dim), 1 / (4 * 0.15)
+    sp = orbitals(2, Emax)
+    fix = np.load(GOLDEN_DIR + "/" + fixture)
+    pv = _load_van(van)
+    vanm = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0])
     flow = cg.FermiNet(2, 16, 16, L)
     pf = flow.unravel(fix["theta"], dim)
     logpsi0 = cg.make_logpsi(flow, sp, L)
@@ -571,21 +587,62 @@ def test_shipped_model_reproduces_published_energies():
     G = cg.kpoints(dim, 15)
     Vconst = n * rs / L * cg.Madelung(dim, 10, G)
     loss = cg.make_loss(log_prob, logpsi, lgl, 10, G, L, rs, Vconst, beta)
-    B = 512
     x = fix["x"][:B].copy()                                        # shipped (already thermalised) walkers
     key = np.random.SeedSequence(5)
-    E, F = [], []
-    for it in range(6):
+    acc_m = {k: [] for k in ("E_mean", "E2_mean", "F_mean", "F2_mean")}
+    for it in range(rounds + 2):
         key, sidx, x, acc = cg.sample_stateindices_and_x(key, sampler, pv, logp, x, pf, 50, 0.1, L)
         if it >= 2:
             obs, _, _ = loss(pv, pf, sidx, x, key)
-            E.append(obs["E_mean"] / rs ** 2); F.append(obs["F_mean"] / rs ** 2)
+            for k in acc_m:
+                acc_m[k].append(obs[k])
     row = fix["data_row"]                                          # epoch F F_std E E_std K K_std V V_std S S_std accept
-    print("shipped n=29 rs=10: E %.4f (published %.4f)  F %.4f (published %.4f)  accept %.3f (published %.3f)"
-          % (np.mean(E), row[3], np.mean(F), row[1], acc, row[11]))
-    assert 0.3 < acc < 0.6
-    assert abs(np.mean(E) - row[3]) < 0.01 * abs(row[3]), (np.mean(E), row[3])
-    assert abs(np.mean(F) - row[1]) < 0.01 * abs(row[1]), (np.mean(F), row[1])
+    ns = B * rounds
+    E, F = np.mean(acc_m["E_mean"]), np.mean(acc_m["F_mean"])
+    sE = np.sqrt(max(np.mean(acc_m["E2_mean"]) - E * E, 0.0) / ns); sF = np.sqrt(max(np.mean(acc_m["F2_mean"]) - F * F, 0.0) / ns)
+    E, F, sE, sF = E / rs ** 2, F / rs ** 2, sE / rs ** 2, sF / rs ** 2
+    print("shipped n=%d rs=%g: E %.4f +- %.4f (published %.4f)  F %.4f +- %.4f (published %.4f)  accept %.3f (published %.3f)"
+          % (n, rs, E, sE, row[3], F, sF, row[1], acc, row[11]))
+    assert 0.15 < acc < 0.65
+    assert abs(E - row[3]) < max(tol * abs(row[3]), 4 * sE), (E, sE, row[3])
+    assert abs(F - row[1]) < max(tol * abs(row[1]), 4 * sF), (F, sF, row[1])
+
+
+def test_epoch1_row_of_the_production_run():
+    """The first row of data/n_29_..._rs_10.0/data.txt (flow ~ identity: freshly initialised N(0, 0.01^2) weights, pretrained
+    Transformer): K 0.6197, V -4.8706, acceptance 0.5369 at the published proposal width -- the cleanest reference-held
+    known answer for sampler + Slater determinant + Ewald sum, here through the HIP path at BASELINE config 4's
+    per-GPU batch: Transformer sampler (host) -> 10 thermalisation rounds -> cg_mcmc / cg_grad_laplacian / cg_ewald."""
+    import coulombgas_amd as cg
+    n, dim, rs, B = 29, 2, 10.0, 2048
+    L, beta = box_length(n, dim), 1 / (4 * 0.15)
+    sp = orbitals(2, 25)
+    pv = _load_van("pretrained_van_n29.npz")
+    vanm = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0])
+    flow = cg.FermiNet(2, 16, 16, L)
+    pf = flow.init(7, np.zeros((n, dim)))                          # src/flow.py:6-14: N(0, 0.01^2) weights, zero biases
+    logpsi0 = cg.make_logpsi(flow, sp, L)
+    logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L)
+    logp = cg.make_logp(logpsi0)
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi0, hutchinson=True, logphi=logphi, logjacdet=logjac)
+    G = cg.kpoints(dim, 15)
+    Vconst = n * rs / L * cg.Madelung(dim, 10, G)
+    loss = cg.make_loss(log_prob, logpsi, lgl, 10, G, L, rs, Vconst, beta)
+    x = np.random.default_rng(11).uniform(0, L, (B, n, dim))       # main.py:236
+    key = np.random.SeedSequence(12)
+    K, V, A = [], [], []
+    for it in range(10 + 3):                                       # main.py:241-246 thermalisation, then three "epochs" of sampling
+        key, sidx, x, acc = cg.sample_stateindices_and_x(key, sampler, pv, logp, x, pf, 50, 0.1, L)
+        if it >= 10:
+            obs, _, _ = loss(pv, pf, sidx, x, key)
+            K.append(obs["K_mean"] / rs ** 2); V.append(obs["V_mean"] / rs ** 2); A.append(acc)
+    row = np.load(GOLDEN_DIR + "/shipped_n29_rs10.npz")["data_row_epoch1"]
+    print("epoch-1 KAT n=29 rs=10: K %.5f (published %.5f)  V %.4f (published %.4f)  accept %.4f (published %.4f)"
+          % (np.mean(K), row[5], np.mean(V), row[7], np.mean(A), row[11]))
+    assert abs(np.mean(K) - row[5]) < 0.005 * row[5]
+    assert abs(np.mean(V) - row[7]) < 0.005 * abs(row[7])
+    assert abs(np.mean(A) - row[11]) < 0.01
 
 
 # ---------------------------------------------------------------------------------------------
