@@ -31,8 +31,7 @@ def main():
     obs_fn, G, Vconst = build_loss(pb)                                     # uses get_comm()
     obs, closs, qloss = obs_fn(pb["logp_states"][sl], pb["theta"], pb["sidx"][sl], pb["x"][sl], pb["v"][sl])
     qv = comm.pmean(np.array(qloss(pb["theta"])))                      # per-device means, pmean'd like main.py:280
-    g, s = qloss.grad(pb["theta"], as_pytree=False)
-    g, s = comm.pmean(g), comm.pmean(s)                                    # main.py:280
+    g, s = qloss.grad(pb["theta"], as_pytree=False, reduce=True)           # main.py:278 + the packed pmean of :280 (the driver's path)
     # sampling call: distinct streams per rank, pmean'd accept rate (src/MCMC.py:39)
     flow = cg.FermiNet(2, 16, 16, pb["L"])
     logp = cg.make_logp(cg.make_logpsi(flow, pb["sp"], pb["L"]))
