@@ -168,11 +168,37 @@ class Transformer:
         return np.concatenate([x1hat, x[..., :-1, :]], axis=-2)                    # :93
 
 
-def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False):
+def flat_params(network, params, dim):
+    """Transformer parameters in the flat order of include/coulombgas.h (cg_van_set_params)."""
+    nm = network.name
+    parts = [params[nm]["x1hat"]]
+    mods = [nm + "/embedding_mlp"]
+    for i in range(network.num_layers):
+        mods += ["%s/layer%d_attn/%s" % (nm, i, part) for part in ("query", "key", "value", "linear")]
+        mods += ["%s/layer%d_mlp/linear" % (nm, i), "%s/layer%d_mlp/linear_1" % (nm, i)]
+    mods.append(nm + "/output_mlp")
+    for m in mods:
+        parts += [params[m]["b"], params[m]["w"]]
+    return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in parts])
+
+
+def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None):
     """src/sampler.py:4-50 with a leading batch axis built in (the reference vmaps).  sampler(params, key, batch) ->
-    (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,)."""
+    (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,).
+    engine (or sampler.attach(engine) later; coulombgas_amd.train does it): a GPU Engine of the same (n, dim) -- the sampler
+    and the log-probability then run on the device (cg_van_sample / cg_van_log_prob: one wave per sample, key / value cache
+    in LDS) and hand DeviceArrays to the hot path; without one this numpy implementation runs on the host.  The gradients
+    (log_prob.grad / .vjp) are host numpy in both cases."""
     sp_indices = np.asarray(sp_indices, dtype=np.float64)
     base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
+    dev = {"engine": engine}
+
+    def _dev_engine(params):
+        eng = dev["engine"]
+        if eng is not None:
+            eng.van_set_params((num_states, network.num_layers, network.model_size, network.num_heads, network.hidden_size),
+                               sp_indices, flat_params(network, params, sp_indices.shape[1]))
+        return eng
 
     def _mask(state_idx):
         state_idx = np.asarray(state_idx)
@@ -183,22 +209,32 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         logits = network.apply(params, None, sp_indices[state_idx])
         return np.where(_mask(state_idx), logits, -1e50)
 
-    def sampler(params, key, batch):
+    def sampler(params, key, batch, unif=None):
+        eng = _dev_engine(params)
+        if eng is not None:
+            from .mcmc import _seed_of
+            return eng.van_sample_d(batch, 0 if unif is not None else _seed_of(key), 0, unif)[0]
         with _blas_limit():
-            return _sampler(params, key, batch)
+            return _sampler(params, key, batch, unif)
 
-    def _sampler(params, key, batch):
+    def _sampler(params, key, batch, unif=None):
         rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
         state_indices = np.zeros((batch, n), dtype=np.int32)
         for i in range(n):
             # the conditional of electron i needs positions <= i only (causal attention): run the prefix, not all n
             logits = network.apply(params, None, sp_indices[state_indices[:, :i + 1]])[:, i, :]
             logits = np.where(_mask(state_indices)[:, i, :], logits, -1e50)
-            g = -np.log(-np.log(rng.uniform(size=logits.shape)))                   # Gumbel-max = jax.random.categorical
+            u = rng.uniform(size=logits.shape) if unif is None else np.asarray(unif)[:, i, :]
+            g = -np.log(-np.log(u))                                                # Gumbel-max = jax.random.categorical
             state_indices[:, i] = np.argmax(logits + g, axis=-1)
         return state_indices
 
     def log_prob(params, state_idx):
+        eng = _dev_engine(params)
+        if eng is not None:
+            if hasattr(state_idx, "ptr"):
+                return eng.van_log_prob_d(state_idx)
+            return eng.van_log_prob(state_idx)
         state_idx = np.asarray(state_idx)
         with _blas_limit():
             logits = _logits(params, state_idx)
@@ -207,7 +243,7 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         return np.take_along_axis(logp, state_idx[..., None], axis=-1)[..., 0].sum(axis=-1)
 
     def _dlogits(params, state_idx):
-        state_idx = np.asarray(state_idx)
+        state_idx = np.asarray(state_idx)                  # (a DeviceArray downloads here: the gradients are host numpy)
         logits, cache = network.forward_cache(params, sp_indices[state_idx])
         logits = np.where(_mask(state_idx), logits, -1e50)
         m = logits.max(axis=-1, keepdims=True)
@@ -229,6 +265,10 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
             return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)
 
     log_prob.grad, log_prob.vjp = grad, vjp
+
+    def attach(engine):
+        dev["engine"] = engine
+    sampler.attach = log_prob.attach = attach
     if mask_fn:
         return _mask, sampler, log_prob
     return sampler, log_prob

@@ -118,6 +118,29 @@ __global__ void __launch_bounds__(256) k_randn(double* __restrict__ out, size_t 
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) out[i] = cg_philox_normal(seed, offset + i, 0x5eedu, 0u);
 }
+// Autoregressive Transformer density matrix (cg_van.hpp): one wave per sample, `waves` samples per workgroup.
+// LDS: [parameters (if plds)] [per-wave scratch: activations + key / value cache].
+template <bool SAMPLE>
+__global__ void __launch_bounds__(256) k_van(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
+                                             int* __restrict__ sidx, const double* __restrict__ unif, uint64_t seed, uint64_t offset,
+                                             double* __restrict__ logp, int plds) {
+    extern __shared__ double van_lds[];
+    const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const double* P = Pg;
+    double* scratch = van_lds;
+    if (plds) {
+        for (int e = threadIdx.x; e < m.total; e += blockDim.x) van_lds[e] = Pg[e];
+        P = van_lds; scratch = van_lds + ((m.total + 1) & ~1);
+        __syncthreads();
+    }
+    double* lw = scratch + (size_t)wave * m.wave_doubles;
+    for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves) {
+        const double lp = cg_van_sequence<SAMPLE>(m, P, sp, sidx + (size_t)s * m.n, lw, unif ? unif + (size_t)s * m.n * m.M : nullptr,
+                                                  seed, offset + (uint64_t)s);
+        if ((threadIdx.x & 63) == 0 && logp) logp[s] = lp;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_axpby(double a, const double* __restrict__ x, double bcoef, double* __restrict__ y, size_t count) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) y[i] = a * x[i] + (bcoef != 0.0 ? bcoef * y[i] : 0.0);
@@ -223,6 +246,8 @@ void cg_destroy(cg_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->bounce) (void)hipHostFree(c->bounce);
     if (c->d_scores) (void)hipFree(c->d_scores);
+    if (c->d_van) (void)hipFree(c->d_van);
+    if (c->d_van_sp) (void)hipFree(c->d_van_sp);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_spk) (void)hipFree(c->d_spk);
     if (c->d_tab) (void)hipFree(c->d_tab);
@@ -421,6 +446,86 @@ int cg_microbench_fp64(cg_ctx* c, int which, double* tflops) {
     return CG_OK;
 }
 
+
+/* ---- autoregressive Transformer density matrix on the device (src/autoregressive.py, src/sampler.py) ---- */
+int cg_van_num_params(int M, int num_layers, int model_size, int num_heads, int hidden_size, int dim) {
+    if (num_layers < 1 || num_layers > CG_VAN_MAXLAYERS || num_heads < 1 || model_size % num_heads) return CG_ERR_ARG;
+    CgVanModel m; return cg_van_model_init(m, M, num_layers, model_size, num_heads, hidden_size, dim, 1);
+}
+int cg_van_set_params(cg_ctx* c, int M, int num_layers, int model_size, int num_heads, int hidden_size,
+                      const double* sp_indices, const double* params) {
+    if (!c || !sp_indices || !params) return CG_ERR_ARG;
+    if (num_layers < 1 || num_layers > CG_VAN_MAXLAYERS || num_heads < 1 || model_size % num_heads || model_size < 1 || model_size > 64 ||
+        hidden_size < 1 || hidden_size > 256 || M < c->n || M > 256 || c->n > 64)
+        CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van_set_params: supported: 1..%d layers, model_size <= 64 divisible by num_heads, hidden_size <= 256, "
+                "n <= %d <= M <= 256 (got layers=%d model=%d heads=%d hidden=%d M=%d n=%d)", CG_VAN_MAXLAYERS, 64, num_layers, model_size, num_heads, hidden_size, M, c->n);
+    CG_HIP(c, hipSetDevice(c->device));
+    CgVanModel m; const int total = cg_van_model_init(m, M, num_layers, model_size, num_heads, hidden_size, c->dim, c->n);
+    if (!c->have_van || c->van.total != total || c->van.M != M) {
+        CG_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_van) { (void)hipFree(c->d_van); c->d_van = nullptr; }
+        if (c->d_van_sp) { (void)hipFree(c->d_van_sp); c->d_van_sp = nullptr; }
+        CG_HIP(c, hipMalloc((void**)&c->d_van, sizeof(double) * total));
+        CG_HIP(c, hipMalloc((void**)&c->d_van_sp, sizeof(double) * (size_t)M * c->dim));
+    }
+    CG_HIP(c, hipMemcpyAsync(c->d_van, params, sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+    CG_HIP(c, hipMemcpyAsync(c->d_van_sp, sp_indices, sizeof(double) * (size_t)M * c->dim, hipMemcpyHostToDevice, c->stream));
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    c->van = m; c->have_van = true;
+    return CG_OK;
+}
+static int van_launch(cg_ctx* c, bool sample, int B, int* sidx_dev, const double* unif_dev, uint64_t seed, uint64_t offset, double* logp_dev) {
+    const CgVanModel& m = c->van;
+    const size_t pbytes = sizeof(double) * (size_t)((m.total + 1) & ~1), wbytes = sizeof(double) * (size_t)m.wave_doubles;
+    int waves = 4, plds = 1;
+    while (waves > 1 && pbytes + waves * wbytes > 160 * 1024) --waves;
+    if (pbytes + waves * wbytes > 160 * 1024) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
+    const size_t lds = (plds ? pbytes : 0) + waves * wbytes;
+    if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van: the key / value cache of one sample needs %zu bytes of LDS", wbytes);
+    const int grid = std::min((B + waves - 1) / waves, c->cu_count * 8);
+    int rc;
+    if (sample) {
+        if ((rc = set_lds(c, k_van<true>, lds))) return rc;
+        hipLaunchKernelGGL(k_van<true>, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
+                           sidx_dev, unif_dev, seed, offset, logp_dev, plds);
+    } else {
+        if ((rc = set_lds(c, k_van<false>, lds))) return rc;
+        hipLaunchKernelGGL(k_van<false>, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
+                           sidx_dev, unif_dev, seed, offset, logp_dev, plds);
+    }
+    return CG_OK;
+}
+int cg_van_log_prob(cg_ctx* c, const int32_t* state_idx, int B, double* logp) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (!c->have_van) CG_FAIL(c, CG_ERR_STATE, "cg_van_log_prob: cg_van_set_params has not been called");
+    if (B == 0) return CG_OK;
+    if (!state_idx || !logp) CG_FAIL(c, CG_ERR_ARG, "cg_van_log_prob: NULL argument");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_van_log_prob: arena");
+    Arg as{(void*)state_idx, nullptr, sizeof(int32_t) * (size_t)B * c->n, true, false};
+    Arg al{logp, nullptr, sizeof(double) * (size_t)B, false, true};
+    if ((rc = stage(c, as)) || (rc = stage(c, al))) return rc;
+    if ((rc = van_launch(c, false, B, (int*)as.dev, nullptr, 0, 0, (double*)al.dev))) return rc;
+    if ((rc = unstage(c, al))) return rc;
+    return finish(c);
+}
+int cg_van_sample(cg_ctx* c, int B, uint64_t seed, uint64_t offset, const double* unif, int32_t* state_idx, double* logp) {
+    if (!c || B < 0) return CG_ERR_ARG;
+    if (!c->have_van) CG_FAIL(c, CG_ERR_STATE, "cg_van_sample: cg_van_set_params has not been called");
+    if (B == 0) return CG_OK;
+    if (!state_idx) CG_FAIL(c, CG_ERR_ARG, "cg_van_sample: state_idx is NULL");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_van_sample: arena");
+    Arg au{(void*)unif, nullptr, sizeof(double) * (size_t)B * c->n * c->van.M, true, false};
+    Arg as{state_idx, nullptr, sizeof(int32_t) * (size_t)B * c->n, false, true};
+    Arg al{logp, nullptr, sizeof(double) * (size_t)B, false, true};
+    if ((rc = stage(c, au)) || (rc = stage(c, as)) || (rc = stage(c, al))) return rc;
+    if ((rc = van_launch(c, true, B, (int*)as.dev, (const double*)au.dev, seed, offset, (double*)al.dev))) return rc;
+    if ((rc = unstage(c, as)) || (rc = unstage(c, al))) return rc;
+    return finish(c);
+}
 
 /* ---- device-resident optimisation step (src/VMC.py:39-76, main.py:277-289) ---- */
 int cg_local_energy(cg_ctx* c, const double* grad, const double* lap, const double* V, const double* logp_states, int B,

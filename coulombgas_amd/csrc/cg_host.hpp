@@ -17,6 +17,7 @@
 #include "cg_flow_fast.hpp"
 #include "cg_dispatch.hpp"
 #include "cg_generic.hpp"
+#include "cg_van.hpp"
 
 // ------------------------------------------------------------------------------------------
 // device-side model descriptor (passed by value to every kernel)
@@ -78,6 +79,7 @@ struct cg_ctx {
     // persistent workspace (derivative kernels)
     void* ws = nullptr; size_t ws_cap = 0;
     double* d_scores = nullptr; size_t scores_cap = 0; int scores_B = 0;     // resident per-sample scores (cg_scores_*)
+    CgVanModel van; double* d_van = nullptr; double* d_van_sp = nullptr; bool have_van = false;   // density-matrix Transformer (cg_van_*)
     std::string err;
 };
 

@@ -202,6 +202,9 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
         thermalise = True
     from .engine import Engine, DeviceArray
     if device_resident and isinstance(eng, Engine):
+        for f in (sampler, log_prob):          # the density-matrix Transformer samples / evaluates on the same GPU
+            if hasattr(f, "attach"):
+                f.attach(eng)
         x = DeviceArray.from_numpy(eng, x)            # the walkers live in HBM from here on (main.py:239: replicate / shard)
     if thermalise:
         for _ in range(mc_therm):                                                      # :241-246

@@ -567,6 +567,54 @@ class Engine:
                        vec.ptr_at(0), vec.ptr_at(3 * P))
         return vec.numpy(3 * P, P)
 
+    # -- density-matrix Transformer on the device (cg_van_*) -------------------------------
+    def van_set_params(self, cfg, sp_indices, flat):
+        """cfg = (M, num_layers, model_size, num_heads, hidden_size); flat: parameters in the order of include/coulombgas.h.
+        Uploads only when something changed."""
+        flat = _f64(flat).ravel(); sp = _f64(sp_indices)
+        key = getattr(self, "_van_key", None)
+        if key is not None and key[0] == tuple(cfg) and np.array_equal(key[1], flat) and np.array_equal(key[2], sp):
+            return
+        M, nl, ms, nh, hs = (int(v) for v in cfg)
+        need = lib().cg_van_num_params(M, nl, ms, nh, hs, self.dim)
+        if need != flat.size:
+            raise ValueError("Transformer parameter count %d, expected %d" % (flat.size, need))
+        check(lib().cg_van_set_params(self._ctx, M, nl, ms, nh, hs, _p(sp), _p(flat)), self._ctx)
+        self._van_key = (tuple(cfg), flat.copy(), sp.copy())
+        self._van_version = getattr(self, "_van_version", 0) + 1
+
+    def van_sample_d(self, B, seed, offset=0, unif=None):
+        """sampler of src/sampler.py:30-38 on the device -> (state_idx (B,n) int32, log p (B)) DeviceArrays"""
+        sidx = self.scratch("van_sidx", (B, self.n), np.int32)
+        logp = self.scratch("van_logp", (B,))
+        u = self.asdevice(unif, "van_unif") if unif is not None else None
+        self._dev_call(lib().cg_van_sample, int(B), int(seed) & (2 ** 64 - 1), int(offset), u.ptr if u is not None else None, sidx.ptr, logp.ptr)
+        sidx.version += 1; logp.version += 1
+        logp.tag = (id(sidx), sidx.version, self._van_version)        # these log-probabilities belong to these samples + parameters
+        return sidx, logp
+
+    def van_log_prob_d(self, sidx_d):
+        cached = self.__dict__.get("_scratch", {}).get("van_logp")
+        if cached is not None and getattr(cached, "tag", None) == (id(sidx_d), sidx_d.version, self._van_version):
+            return cached                                                # computed by the sampling pass itself
+        logp = self.scratch("van_logp2", (sidx_d.shape[0],))
+        self._dev_call(lib().cg_van_log_prob, sidx_d.ptr, int(sidx_d.shape[0]), logp.ptr)
+        logp.version += 1
+        return logp
+
+    def van_log_prob(self, state_idx):
+        s = _i32(state_idx).reshape(-1, self.n)
+        out = np.empty(s.shape[0])
+        check(lib().cg_van_log_prob(self._ctx, _p(s), s.shape[0], _p(out)), self._ctx)
+        return out.reshape(np.shape(state_idx)[:-1])
+
+    def van_sample(self, B, seed, offset=0, unif=None):
+        s = np.empty((B, self.n), dtype=np.int32); lp = np.empty(B)
+        if unif is not None:
+            unif = _f64(unif).reshape(B, self.n, -1)
+        check(lib().cg_van_sample(self._ctx, int(B), int(seed) & (2 ** 64 - 1), int(offset), _p(unif), _p(s), _p(lp)), self._ctx)
+        return s, lp
+
     # -- device-pointer API (DeviceBuffer in / out, asynchronous) ---------------------
     def mcmc_dev(self, x_buf, sidx_buf, B, mc_steps, mc_stddev, seed=0, walker_offset=0, logp_buf=None):
         assert self._mode == _lib.CG_PTR_DEVICE

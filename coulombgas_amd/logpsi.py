@@ -59,7 +59,8 @@ def make_logp(logpsi):
 
     class BoundLogp:
         def __init__(self, params, state_indices):
-            self.wf, self.params, self.state_indices = wf, params, np.ascontiguousarray(state_indices, dtype=np.int32)
+            self.wf, self.params = wf, params
+            self.state_indices = state_indices if hasattr(state_indices, "ptr") else np.ascontiguousarray(state_indices, dtype=np.int32)
 
         def __call__(self, x):
             return logp(x, self.params, self.state_indices)

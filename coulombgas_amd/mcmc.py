@@ -31,7 +31,8 @@ def mcmc(logp_fn, x_init, key, mc_steps, mc_stddev=0.02, noise=None, unif=None, 
         x_d = x_init
     else:
         x_d = eng.asdevice(np.asarray(x_init, dtype=np.float64).reshape((batch,) + tuple(np.shape(x_init)[-2:])), "x_chain")
-    s_d = eng.asdevice(np.asarray(logp_fn.state_indices).reshape(batch, -1), "sidx", np.int32)
+    si = logp_fn.state_indices
+    s_d = si if hasattr(si, "ptr") else eng.asdevice(np.asarray(si).reshape(batch, -1), "sidx", np.int32)
     nacc = eng.mcmc_d(x_d, s_d, mc_steps, mc_stddev, seed=_seed_of(key), walker_offset=walker_offset, noise=noise, unif=unif)
     if wrap_L is not None:
         eng.wrap_d(x_d)

@@ -20,7 +20,9 @@ def sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc
     ss = key if isinstance(key, np.random.SeedSequence) else np.random.SeedSequence(int(key))
     key, key_state, key_MCMC = ss.spawn(3)                                    # jax.random.split(key, 3), :20
     batch = np.shape(x)[0]
-    state_indices = np.asarray(sampler(params_van, key_state, batch), dtype=np.int32)
+    state_indices = sampler(params_van, key_state, batch)          # a device-side sampler hands back a DeviceArray
+    if not hasattr(state_indices, "ptr"):
+        state_indices = np.asarray(state_indices, dtype=np.int32)
     comm = comm or get_comm()
     x, accept_rate = mcmc(logp.bind(params_flow, state_indices), x, key_MCMC, mc_steps, mc_stddev,
                           walker_offset=comm.rank * batch, comm=comm, wrap_L=L)     # :23-24 (wrap fused into the call)
@@ -50,10 +52,14 @@ def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, 
         eng.set_ewald(kappa, G, rs)
         x_d = eng.asdevice(x, "x")
         s_d = eng.asdevice(state_indices, "sidx", np.int32)
-        logp_states = np.asarray(log_prob(params_van, state_indices), dtype=np.float64)     # classical model: host side
+        lps = log_prob(params_van, state_indices)                                            # :34 (device Transformer: a DeviceArray)
+        if hasattr(lps, "ptr"):
+            lps_d = lps
+        else:
+            lps = np.asarray(lps, dtype=np.float64)
+            lps_d = eng.asdevice(lps, "logp_states") if lps.any() else None
         grad, laplacian = logpsi_grad_laplacian(x_d, params_flow, s_d, key)                  # :35, stays on the device
         V = eng.ewald_d(x_d)                                                                 # :40
-        lps_d = eng.asdevice(logp_states, "logp_states") if logp_states.any() else None
         Eloc, Floc, mom = eng.local_energy_d(grad, laplacian, V, lps_d, Vconst, beta)       # :39-42 + local means of :46-53
         cm.pmean_d(mom)                                                                      # :44-53, one 10-double all-reduce
         vals = eng.to_host(mom)

@@ -145,6 +145,25 @@ int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
  * 1/2 of d/dtheta of quantum_score = 2 mean Re logPsi, src/VMC.py:75, main.py:278) */
 int cg_scores_mean(cg_ctx* ctx, double* score_mean);
 
+/* ---- density matrix: autoregressive Transformer over momentum occupations, on the device ----------------- */
+
+/* Transformer(output_size = M, num_layers, model_size, num_heads, hidden_size) of src/autoregressive.py:50-96 with the sampler
+ * and log-probability of src/sampler.py:4-50 for the ctx's n electrons in M orbitals (n <= 64, M <= 256).
+ * sp_indices (M x dim): the table make_autoregressive_sampler receives (main.py:107: sp_indices_twist), HOST pointer.
+ * params: HOST pointer, cg_van_num_params(...) doubles in the order
+ *   x1hat[M]; embedding_mlp b[ms], w[dim][ms]; per layer: query b, w[ms][ms]; key b, w; value b, w; attention linear b, w;
+ *   layer_mlp/linear b[hs], w[ms][hs]; layer_mlp/linear_1 b[ms], w[hs][ms]; output_mlp b[M], w[ms][M]   (w row-major (in, out)). */
+int cg_van_num_params(int M, int num_layers, int model_size, int num_heads, int hidden_size, int dim);
+int cg_van_set_params(cg_ctx* ctx, int M, int num_layers, int model_size, int num_heads, int hidden_size,
+                      const double* sp_indices, const double* params);
+/* logp (B) = vmap(log_prob)(params, state_idx (B,n))   src/sampler.py:40-44 */
+int cg_van_log_prob(cg_ctx* ctx, const int32_t* state_idx, int B, double* logp);
+/* state_idx (B,n) = sampler(params, key, B)   src/sampler.py:30-38: n sequential conditionals, jax.random.categorical as
+ * Gumbel-max.  unif: nullable (B,n,M) uniforms in (0,1) replacing the random draws (parity mode); NULL: the in-library
+ * Philox stream (seed, offset + sample).  logp: nullable (B): log-probabilities of the drawn samples (saves the
+ * log_prob(params_van, state_indices) pass of src/VMC.py:34). */
+int cg_van_sample(cg_ctx* ctx, int B, uint64_t seed, uint64_t offset, const double* unif, int32_t* state_idx, double* logp);
+
 /* ---- local energy and loss weights on the device (K8) ----------------------------------------------------- */
 
 /* src/VMC.py:39-58 for ONE device, before the pmean: from grad (B,n,dim,2), lap (B,2) of cg_grad_laplacian and V (B) of

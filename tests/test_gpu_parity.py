@@ -577,8 +577,9 @@ def test_shipped_model_reproduces_published_energies(n, rs, Emax, fixture, van, 
     fix = np.load(GOLDEN_DIR + "/" + fixture)
     pv = _load_van(van)
     vanm = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
-    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0])
     flow = cg.FermiNet(2, 16, 16, L)
+    # the density matrix samples and evaluates on the same GPU: state indices and log-probabilities never visit the host
+    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0], engine=flow.engine(n, dim, sp))
     pf = flow.unravel(fix["theta"], dim)
     logpsi0 = cg.make_logpsi(flow, sp, L)
     logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L)
@@ -587,7 +588,8 @@ def test_shipped_model_reproduces_published_energies(n, rs, Emax, fixture, van, 
     G = cg.kpoints(dim, 15)
     Vconst = n * rs / L * cg.Madelung(dim, 10, G)
     loss = cg.make_loss(log_prob, logpsi, lgl, 10, G, L, rs, Vconst, beta)
-    x = fix["x"][:B].copy()                                        # shipped (already thermalised) walkers
+    from coulombgas_amd.engine import DeviceArray
+    x = DeviceArray.from_numpy(flow.engine(n, dim, sp), fix["x"][:B])          # shipped (already thermalised) walkers, kept in HBM
     key = np.random.SeedSequence(5)
     acc_m = {k: [] for k in ("E_mean", "E2_mean", "F_mean", "F2_mean")}
     for it in range(rounds + 2):
@@ -619,8 +621,8 @@ def test_epoch1_row_of_the_production_run():
     sp = orbitals(2, 25)
     pv = _load_van("pretrained_van_n29.npz")
     vanm = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
-    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0])
     flow = cg.FermiNet(2, 16, 16, L)
+    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0], engine=flow.engine(n, dim, sp))
     pf = flow.init(7, np.zeros((n, dim)))                          # src/flow.py:6-14: N(0, 0.01^2) weights, zero biases
     logpsi0 = cg.make_logpsi(flow, sp, L)
     logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L)
@@ -787,4 +789,102 @@ def test_grad_laplacian_n57_all_memory_placements():
     olib.cgo_ewald(n, dim, C.c_double(L), C.c_double(10.0), C.c_double(10.0), Gl.ctypes.data_as(C.c_void_p), Gl.shape[0],
                    xc.ctypes.data_as(C.c_void_p), B, Vr.ctypes.data_as(C.c_void_p))
     assert np.abs(V - Vr).max() < 1e-10 * np.abs(Vr).max()
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# f2: the autoregressive Transformer density matrix on the device (cg_van_sample / cg_van_log_prob)
+# ---------------------------------------------------------------------------------------------
+def test_transformer_density_matrix_on_device():
+    """src/autoregressive.py:50-96 + src/sampler.py:4-50 as device kernels (one wave per sample, key / value cache in LDS):
+    (i) the reference's own KAT tests/test_sampler.py:40-69: the probabilities of all C(10,4) ordered occupations sum to one;
+    (ii) log-probabilities against the oracle's torch restatement with perturbed weights; (iii) the sampler with supplied
+    uniforms against the host restatement of jax.random.categorical, and its by-product log-probabilities; (iv) the Philox
+    sampler's empirical frequencies against the exact probabilities; (v) the shipped pretrained n = 13 model: F, E, S of its
+    published data.txt row; (vi) the shipped n = 57 model (M = 149 orbitals) against the host implementation."""
+    import itertools
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    from oracle import cg_ref as R
+    dim = 2
+    # (i) + (iv) n = 4 electrons in M = 10 orbitals
+    n, M = 4, 10
+    sp10 = orbitals(2)[-M:]
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp10)
+    van = cg.Transformer(M, 2, 16, 4, 32)
+    rng = np.random.default_rng(4)
+    params = van.init(rng, sp10[:n])
+    for mod in params:
+        for leaf in params[mod]:
+            params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp10, n, M, engine=eng)
+    states = np.array(list(itertools.combinations(range(M), n)), dtype=np.int32)
+    lp_all = log_prob(params, states)
+    assert np.exp(lp_all).sum() == pytest.approx(1.0, abs=1e-12)
+    tp = {m: {l: R.T(v) for l, v in params[m].items()} for m in params}
+    lr = np.array([float(R.autoregressive_log_prob(tp, torch.as_tensor(s.astype(np.int64)), R.T(sp10), 2, 4)) for s in states])
+    assert np.abs(lp_all - lr).max() < 1e-12 * np.abs(lr).max()
+    B = 200000
+    s_d = sampler(params, 11, B)
+    s = np.asarray(s_d)
+    assert s.shape == (B, n) and (np.diff(s, axis=1) > 0).all() and s.min() >= 0 and s.max() < M
+    assert np.abs(np.asarray(log_prob(params, s_d)) - log_prob(params, s)).max() < 1e-12           # by-product of the sampling pass
+    code = {tuple(st): i for i, st in enumerate(states.tolist())}
+    counts = np.bincount([code[tuple(r)] for r in s.tolist()], minlength=len(states))
+    p = np.exp(lr)
+    chi2 = ((counts - B * p) ** 2 / (B * p)).sum()
+    assert chi2 < len(states) + 6 * np.sqrt(2 * len(states)), chi2                               # chi-square, 209 d.o.f.
+    # (iii) supplied uniforms: identical draws to the host restatement
+    hs, hlp = cg.make_autoregressive_sampler(van, sp10, n, M)
+    u = rng.uniform(size=(512, n, M))
+    assert np.array_equal(np.asarray(sampler(params, 0, 512, unif=u)), hs(params, 0, 512, unif=u))
+    eng.close()
+    # (ii) n = 5, M = 12 against the oracle
+    n, M = 5, 12
+    sp = orbitals(2)[-M:]
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp)
+    van = cg.Transformer(M, 2, 16, 4, 32)
+    params = van.init(rng, sp[:n])
+    for mod in params:
+        for leaf in params[mod]:
+            params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M, engine=eng)
+    s = np.asarray(sampler(params, 2, 64))
+    tp = {m: {l: R.T(v) for l, v in params[m].items()} for m in params}
+    lr = np.array([float(R.autoregressive_log_prob(tp, torch.as_tensor(r.astype(np.int64)), R.T(sp), 2, 4)) for r in s])
+    assert np.abs(log_prob(params, s) - lr).max() < 1e-12 * np.abs(lr).max()
+    eng.close()
+    # (v) shipped pretrained model, n = 13 (published free-fermion row: epoch, F, F_std, E, E_std, S, S_std)
+    n, Theta = 13, 0.15
+    L, beta = box_length(n, dim), 1 / (4 * Theta)
+    spt = orbitals(2, 25)
+    z = np.load(GOLDEN_DIR + "/pretrained_van_n13.npz")
+    pv = _load_van("pretrained_van_n13.npz")
+    eng = Engine(n, dim, 2, 16, 16, L, spt)
+    van = cg.Transformer(spt.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, spt, n, spt.shape[0], engine=eng)
+    Es = (2 * np.pi / L) ** 2 * (spt ** 2).sum(-1)                                    # src/freefermion/pretraining.py:54
+    B = 65536
+    s_d = sampler(pv, 1, B)
+    s, lp = np.asarray(s_d), np.asarray(log_prob(pv, s_d))
+    F = lp / beta + Es[s].sum(-1)
+    row = z["data_row_last"]
+    print("pretrained n=13 on the device: F %.6f +- %.6f (published %.6f)  E %.4f (published %.4f)  S %.4f (published %.4f)"
+          % (F.mean(), F.std() / np.sqrt(B), row[1], Es[s].sum(-1).mean(), row[3], -lp.mean(), row[5]))
+    assert abs(F.mean() - row[1]) < 5 * np.hypot(F.std() / np.sqrt(B), row[2])
+    assert abs(Es[s].sum(-1).mean() - row[3]) < 5 * np.hypot(Es[s].sum(-1).std() / np.sqrt(B), row[4])
+    assert abs(-lp.mean() - row[5]) < 5 * np.hypot(lp.std() / np.sqrt(B), row[6])
+    eng.close()
+    # (vi) shipped n = 57 model: M = 149 orbitals (three lanes-rounds of logits, 57-position attention)
+    n = 57
+    sp49 = orbitals(2, 49)
+    pv = _load_van("shipped_n57_rs10_van.npz")
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp49)
+    van = cg.Transformer(sp49.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], engine=eng)
+    _, hlp = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0])
+    s = np.asarray(sampler(pv, 5, 96))
+    assert (np.diff(s, axis=1) > 0).all() and s.max() < sp49.shape[0]
+    ref = hlp(pv, s)
+    assert np.abs(log_prob(pv, s) - ref).max() < 1e-11 * np.abs(ref).max()
     eng.close()

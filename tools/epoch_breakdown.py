@@ -11,6 +11,17 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 L = box_length(n, 2); sp = orbitals(2, {13: 25, 29: 25, 57: 49}.get(n, 25)); rs = 10.0
 flow = cg.FermiNet(2, 16, 16, L); p0 = flow.init(1, np.zeros((n, 2)))
 samp = cg.GroundStateSampler(n, sp.shape[0])
+pv = None
+if "--van" in sys.argv:                      # finite temperature: the shipped Transformer density matrix, sampled on the GPU
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                             {13: "pretrained_van_n13.npz", 29: "shipped_n29_rs10_van.npz", 57: "shipped_n57_rs10_van.npz"}[n]))
+    pv = {}
+    for k in z.files:
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    s_fn, lp_fn = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=None if "--host-van" in sys.argv else flow.engine(n, 2, sp))
+    samp = s_fn; samp.log_prob = lp_fn
 G = cg.kpoints(2, 15); Vconst = n * rs / L * cg.Madelung(2, 10, G)
 lp0 = cg.make_logpsi(flow, sp, L); logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L); logp = cg.make_logp(lp0)
 logpsi, lgl = cg.make_logpsi_grad_laplacian(lp0, hutchinson=True, logphi=logphi, logjacdet=logjac)
@@ -25,10 +36,10 @@ def tm(name, fn):
     t0 = time.perf_counter(); r = fn(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0; return r
 for ep in range(4):
     if ep == 1: T.clear()
-    key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, None, logp, x, p0, 50, 0.1, L))
-    data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(None, p0, sidx, x, key))
+    key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, pv, logp, x, p0, 50, 0.1, L))
+    data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(pv, p0, sidx, x, key))
     g, s = tm("quantum grad (scores + VJP)", lambda: qloss.grad(p0, reduce=True))
-    f = tm("fishers_fn", lambda: fishers_fn(None, p0, sidx, x))
+    f = tm("fishers_fn", lambda: fishers_fn(pv, p0, sidx, x))
     gf = {k: {l: g[k][l] - data["E_mean"] * s[k][l] for l in g[k]} for k in g}
     (uv, uf), _ = tm("SR solve+clip", lambda: opt.update((None, gf), None, f))
     p0 = tm("apply", lambda: cg.apply_updates(p0, uf))
