@@ -888,3 +888,31 @@ def test_transformer_density_matrix_on_device():
     ref = hlp(pv, s)
     assert np.abs(log_prob(pv, s) - ref).max() < 1e-11 * np.abs(ref).max()
     eng.close()
+
+
+def test_freefermion_pretraining_on_device():
+    """f4 (src/freefermion/pretraining.py:34-108) with the density matrix sampled and evaluated on the GPU and the classical
+    Fisher matrix formed there: natural-gradient pre-training of a small Transformer lowers F = <log p / beta + E> towards the
+    exact canonical free energy of non-interacting fermions (brute-force enumeration), never below it."""
+    import itertools
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    from coulombgas_amd.freefermion import exact_free_energy
+    n, Theta, dim = 4, 0.15, 2
+    L, beta = box_length(n, dim), 1 / (4 * Theta)
+    sp10 = orbitals(2, 25)[-10:]
+    Es = (2 * np.pi / L) ** 2 * (sp10 ** 2).sum(-1)
+    Etot = np.array([Es[list(c)].sum() for c in itertools.combinations(range(10), n)])
+    w = np.exp(-beta * (Etot - Etot.min()))
+    F_exact = Etot.min() - np.log(w.sum()) / beta
+    assert exact_free_energy(Es, n, beta)[0] == pytest.approx(F_exact, rel=1e-13)
+    eng = Engine(n, dim, 2, 16, 16, L, sp10)
+    van = cg.Transformer(10, 1, 8, 2, 16)
+    p0 = van.init(5, sp10[:n])
+    pv, rows = cg.pretrain(van, p0, n, dim, Theta, sp10, 11, sr=True, damping=1e-3, max_norm=1e-2, batch=4096, epoch=60, engine=eng)
+    v = np.array([[float(t) for t in r.split()] for r in rows])
+    assert v.shape == (60, 7) and np.isfinite(v).all()
+    assert v[-5:, 1].mean() < v[0, 1] - 5 * v[0, 2]               # F went down by many standard errors
+    assert v[-5:, 1].mean() > F_exact - 5 * v[-5:, 2].mean()      # ... and respects the variational bound
+    print("pre-training on the device: F %.5f -> %.5f (exact %.5f)" % (v[0, 1], v[-5:, 1].mean(), F_exact))
+    eng.close()
