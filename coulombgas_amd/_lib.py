@@ -68,6 +68,10 @@ PROTOTYPES = {
     "cg_van_set_params": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cg_van_log_prob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cg_van_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_van_scores_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "cg_van_scores_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_van_scores_fisher": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cg_van_scores_get": (C.c_int, [C.c_void_p, C.c_void_p]),
     "cg_local_energy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_abs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

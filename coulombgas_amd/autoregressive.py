@@ -172,14 +172,61 @@ def flat_params(network, params, dim):
     """Transformer parameters in the flat order of include/coulombgas.h (cg_van_set_params)."""
     nm = network.name
     parts = [params[nm]["x1hat"]]
+    for m in _flat_modules(network):
+        parts += [params[m]["b"], params[m]["w"]]
+    return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in parts])
+
+
+def _flat_modules(network):
+    nm = network.name
     mods = [nm + "/embedding_mlp"]
     for i in range(network.num_layers):
         mods += ["%s/layer%d_attn/%s" % (nm, i, part) for part in ("query", "key", "value", "linear")]
         mods += ["%s/layer%d_mlp/linear" % (nm, i), "%s/layer%d_mlp/linear_1" % (nm, i)]
-    mods.append(nm + "/output_mlp")
-    for m in mods:
-        parts += [params[m]["b"], params[m]["w"]]
-    return np.concatenate([np.asarray(a, dtype=np.float64).ravel() for a in parts])
+    return mods + [nm + "/output_mlp"]
+
+
+def unflat_params(network, flat, dim):
+    """inverse of flat_params; flat may carry leading axes (per-sample gradients)"""
+    flat = np.asarray(flat)
+    lead, shapes, off = flat.shape[:-1], network.param_shapes(dim), 0
+    out = {}
+
+    def take(shp):
+        nonlocal off
+        sz = int(np.prod(shp)); a = flat[..., off:off + sz].reshape(lead + tuple(shp)); off += sz
+        return a
+    out[network.name] = {"x1hat": take(shapes[network.name]["x1hat"])}
+    for m in _flat_modules(network):
+        b = take(shapes[m]["b"]); out[m] = {"b": b, "w": take(shapes[m]["w"])}
+    assert off == flat.shape[-1]
+    return out
+
+
+class DeviceScores:
+    """Per-sample gradients of log p held on the GPU (cg_van_scores_compute).  hybrid_fisher_sr takes the Fisher matrix from
+    .fisher_d() without the (B, P) matrix visiting the host; np.asarray(.) / .tree() download it (tests, diagnostics).  All
+    host-visible results are in ravel_pytree order (sorted keys, like jax.flatten_util) -- perm maps it to the device's."""
+
+    def __init__(self, engine, network, dim, B):
+        from .sr import ravel_pytree
+        self.engine, self.network, self.dim, self.B = engine, network, dim, B
+        n = sum(int(np.prod(shp)) for leaves in network.param_shapes(dim).values() for shp in leaves.values())
+        self.perm = ravel_pytree(unflat_params(network, np.arange(n), dim))[0].astype(np.int32)
+        self.shape = (B, n)
+
+    def fisher_d(self):
+        return self.engine.van_scores_fisher_d(self.perm)
+
+    def flat(self):
+        return self.engine.van_scores_get()                     # (B, P) in the device's flat order
+
+    def tree(self):
+        return unflat_params(self.network, self.flat(), self.dim)
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.flat()[:, self.perm]
+        return a if dtype is None else a.astype(dtype)
 
 
 def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None):
@@ -187,8 +234,8 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
     (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,).
     engine (or sampler.attach(engine) later; coulombgas_amd.train does it): a GPU Engine of the same (n, dim) -- the sampler
     and the log-probability then run on the device (cg_van_sample / cg_van_log_prob: one wave per sample, key / value cache
-    in LDS) and hand DeviceArrays to the hot path; without one this numpy implementation runs on the host.  The gradients
-    (log_prob.grad / .vjp) are host numpy in both cases."""
+    in LDS) and hand DeviceArrays to the hot path, and the gradients (log_prob.grad -> DeviceScores, log_prob.vjp) come from
+    the device's reverse pass (cg_van_scores_*); without one this numpy implementation runs on the host."""
     sp_indices = np.asarray(sp_indices, dtype=np.float64)
     base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
     dev = {"engine": engine}
@@ -252,14 +299,31 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         np.put_along_axis(d, state_idx[..., None], np.take_along_axis(d, state_idx[..., None], axis=-1) + 1.0, axis=-1)
         return d, cache                                       # d log p / d logits = onehot - softmax (0 on masked entries)
 
+    def _dev_scores(params, state_idx):
+        eng = _dev_engine(params)
+        if eng is None:
+            return None
+        s_d = state_idx if hasattr(state_idx, "ptr") else eng.asdevice(np.asarray(state_idx, dtype=np.int32), "van_sidx_in", np.int32)
+        eng.van_scores_compute_d(s_d)
+        return eng
+
     def grad(params, state_idx):
-        """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients, every leaf with a leading batch axis."""
+        """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients, every leaf with a leading batch axis (host), or
+        a DeviceScores handle with an engine attached."""
+        eng = _dev_scores(params, state_idx)
+        if eng is not None:
+            return DeviceScores(eng, network, sp_indices.shape[1], int(np.shape(state_idx)[0]))
         with _blas_limit():
             d, cache = _dlogits(params, state_idx)
             return network.backward(params, cache, d, per_sample=True)
 
     def vjp(params, state_idx, w):
         """sum_b w[b] * d log_prob_b / d params  (what jax.jacrev of a weighted sum of log-probabilities returns)."""
+        eng = _dev_scores(params, state_idx)
+        if eng is not None:
+            w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w")
+            g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1],)))
+            return unflat_params(network, eng.to_host(g), sp_indices.shape[1])
         with _blas_limit():
             d, cache = _dlogits(params, state_idx)
             return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)

@@ -141,6 +141,41 @@ __global__ void __launch_bounds__(256) k_van(CgVanModel m, const double* __restr
     }
 }
 
+// per-sample gradients of log p (cg_van_gradient): one wave per sample; stash: (n-1) * token-stash doubles per wave in HBM
+__global__ void __launch_bounds__(256) k_van_grad(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
+                                                  const int* __restrict__ sidx, double* __restrict__ S, double* __restrict__ stash_all, int plds) {
+    extern __shared__ double van_lds[];
+    const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const double* P = Pg;
+    double* scratch = van_lds;
+    if (plds) {
+        for (int e = threadIdx.x; e < m.total; e += blockDim.x) van_lds[e] = Pg[e];
+        P = van_lds; scratch = van_lds + ((m.total + 1) & ~1);
+        __syncthreads();
+    }
+    double* lw = scratch + (size_t)wave * cg_van_grad_wave_doubles(m);
+    double* stash = stash_all + (size_t)(blockIdx.x * waves + wave) * (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
+    for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves)
+        cg_van_gradient(m, P, sp, sidx + (size_t)s * m.n, lw, stash, S + (size_t)s * m.total);
+}
+// out[slice][p] = sum_{b in slice} w[b] S[b][p] for a real (B x P) matrix (the classical theta-VJP from resident scores)
+__global__ void __launch_bounds__(256) k_gemv_t(const double* __restrict__ S, const double* __restrict__ w, int B, int P, int chunk,
+                                                double* __restrict__ out) {
+    __shared__ double part[256];
+    const int p = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * chunk, b1 = min(B, b0 + chunk);
+    double a = 0.0;
+    if (p < P) for (int b = b0 + rg; b < b1; b += 4) a = fma(w[b], S[(size_t)b * P + p], a);
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (rg == 0 && p < P) out[(size_t)blockIdx.y * P + p] = part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192];
+}
+
+// out[i][j] = in[perm[i]][perm[j]]: the classical Fisher matrix from the device's flat parameter order to the caller's
+__global__ void __launch_bounds__(256) k_permute_sym(const double* __restrict__ in, const int* __restrict__ perm, int P, double* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j < P) out[(size_t)i * P + j] = in[(size_t)perm[i] * P + perm[j]];
+}
 __global__ void __launch_bounds__(256) k_axpby(double a, const double* __restrict__ x, double bcoef, double* __restrict__ y, size_t count) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < count) y[i] = a * x[i] + (bcoef != 0.0 ? bcoef * y[i] : 0.0);
@@ -247,6 +282,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->bounce) (void)hipHostFree(c->bounce);
     if (c->d_scores) (void)hipFree(c->d_scores);
     if (c->d_van) (void)hipFree(c->d_van);
+    if (c->d_van_scores) (void)hipFree(c->d_van_scores);
     if (c->d_van_sp) (void)hipFree(c->d_van_sp);
     if (c->d_theta) (void)hipFree(c->d_theta);
     if (c->d_spk) (void)hipFree(c->d_spk);
@@ -524,6 +560,85 @@ int cg_van_sample(cg_ctx* c, int B, uint64_t seed, uint64_t offset, const double
     if ((rc = stage(c, au)) || (rc = stage(c, as)) || (rc = stage(c, al))) return rc;
     if ((rc = van_launch(c, true, B, (int*)as.dev, (const double*)au.dev, seed, offset, (double*)al.dev))) return rc;
     if ((rc = unstage(c, as)) || (rc = unstage(c, al))) return rc;
+    return finish(c);
+}
+
+/* classical scores d log p_b / d params (flat parameter order), resident on the device like the quantum scores */
+int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
+    if (!c || B <= 0) return CG_ERR_ARG;
+    if (!c->have_van) CG_FAIL(c, CG_ERR_STATE, "cg_van_scores_compute: cg_van_set_params has not been called");
+    if (!state_idx) CG_FAIL(c, CG_ERR_ARG, "cg_van_scores_compute: state_idx is NULL");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_van_scores_compute: arena");
+    const CgVanModel& m = c->van;
+    Arg as{(void*)state_idx, nullptr, sizeof(int32_t) * (size_t)B * c->n, true, false};
+    if ((rc = stage(c, as))) return rc;
+    const size_t need = sizeof(double) * (size_t)B * m.total;
+    if (c->van_scores_cap < need) {
+        CG_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_van_scores) { (void)hipFree(c->d_van_scores); c->d_van_scores = nullptr; c->van_scores_cap = 0; }
+        if (hipMalloc((void**)&c->d_van_scores, need) != hipSuccess) CG_FAIL(c, CG_ERR_HIP, "cg_van_scores_compute: %zu bytes for the classical scores could not be allocated", need);
+        c->van_scores_cap = need;
+    }
+    const size_t pbytes = sizeof(double) * (size_t)((m.total + 1) & ~1), wbytes = sizeof(double) * (size_t)cg_van_grad_wave_doubles(m);
+    int waves = 4, plds = 1;
+    while (waves > 1 && pbytes + waves * wbytes > 160 * 1024) --waves;
+    if (pbytes + waves * wbytes > 160 * 1024) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
+    const size_t lds = (plds ? pbytes : 0) + waves * wbytes;
+    if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van_scores_compute: one sample needs %zu bytes of LDS", wbytes);
+    const int grid = std::min((B + waves - 1) / waves, c->cu_count * 4);
+    const size_t stash_per_wave = (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
+    if ((rc = ensure_ws(c, sizeof(double) * stash_per_wave * (size_t)grid * waves))) return rc;
+    if ((rc = set_lds(c, k_van_grad, lds))) return rc;
+    hipLaunchKernelGGL(k_van_grad, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
+                       (const int*)as.dev, c->d_van_scores, (double*)c->ws, plds);
+    c->van_scores_B = B;
+    return finish(c);
+}
+int cg_van_scores_get(cg_ctx* c, double* scores) {
+    if (!c || !scores) return CG_ERR_ARG;
+    if (!c->d_van_scores || c->van_scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_van_scores_get: cg_van_scores_compute has not been called");
+    CG_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = sizeof(double) * (size_t)c->van_scores_B * c->van.total;
+    CG_HIP(c, hipMemcpyAsync(scores, c->d_van_scores, bytes, c->ptr_mode == CG_PTR_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+int cg_van_scores_vjp(cg_ctx* c, const double* w, double* g) {
+    if (!c || !w || !g) return CG_ERR_ARG;
+    if (!c->d_van_scores || c->van_scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_van_scores_vjp: cg_van_scores_compute has not been called");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int B = c->van_scores_B, P = c->van.total;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_van_scores_vjp: arena");
+    Arg aw{(void*)w, nullptr, sizeof(double) * (size_t)B, true, false};
+    Arg ag{g, nullptr, sizeof(double) * (size_t)P, false, true};
+    if ((rc = stage(c, aw)) || (rc = stage(c, ag))) return rc;
+    const int nsl = std::max(1, std::min(64, (B + 63) / 64)), chunk = (B + nsl - 1) / nsl;
+    double* partial = (double*)arena_take(c, sizeof(double) * (size_t)nsl * P);
+    if (!partial) CG_FAIL(c, CG_ERR_HIP, "cg_van_scores_vjp: workspace allocation failed");
+    hipLaunchKernelGGL(k_gemv_t, dim3((P + 63) / 64, nsl), dim3(256), 0, c->stream, (const double*)c->d_van_scores, (const double*)aw.dev, B, P, chunk, partial);
+    hipLaunchKernelGGL(k_rows_sum, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, nsl, P, 1.0, (double*)ag.dev);
+    if ((rc = unstage(c, ag))) return rc;
+    return finish(c);
+}
+int cg_van_scores_fisher(cg_ctx* c, const int32_t* perm, double* fisher) {
+    if (!c || !fisher) return CG_ERR_ARG;
+    if (!c->d_van_scores || c->van_scores_B <= 0) CG_FAIL(c, CG_ERR_STATE, "cg_van_scores_fisher: cg_van_scores_compute has not been called");
+    CG_HIP(c, hipSetDevice(c->device));
+    int rc; const int P = c->van.total;
+    if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_van_scores_fisher: arena");
+    Arg af{fisher, nullptr, sizeof(double) * (size_t)P * P, false, true};
+    if ((rc = stage(c, af))) return rc;
+    double* raw = (double*)af.dev;
+    Arg ap{(void*)perm, nullptr, sizeof(int32_t) * (size_t)P, true, false};
+    if (perm) {
+        if ((rc = stage(c, ap))) return rc;
+        raw = (double*)arena_take(c, sizeof(double) * (size_t)P * P);
+        if (!raw) CG_FAIL(c, CG_ERR_HIP, "cg_van_scores_fisher: workspace allocation failed");
+    }
+    if ((rc = cg_fisher_real_nr(c, c->d_van_scores, c->van_scores_B, P, raw))) return rc;
+    if (perm) hipLaunchKernelGGL(k_permute_sym, dim3((P + 255) / 256, P), dim3(256), 0, c->stream, (const double*)raw, (const int*)ap.dev, P, (double*)af.dev);
+    if ((rc = unstage(c, af))) return rc;
     return finish(c);
 }
 

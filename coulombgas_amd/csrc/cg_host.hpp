@@ -80,6 +80,7 @@ struct cg_ctx {
     void* ws = nullptr; size_t ws_cap = 0;
     double* d_scores = nullptr; size_t scores_cap = 0; int scores_B = 0;     // resident per-sample scores (cg_scores_*)
     CgVanModel van; double* d_van = nullptr; double* d_van_sp = nullptr; bool have_van = false;   // density-matrix Transformer (cg_van_*)
+    double* d_van_scores = nullptr; size_t van_scores_cap = 0; int van_scores_B = 0;              // resident classical scores
     std::string err;
 };
 
@@ -208,3 +209,4 @@ int cg_gen_run_mcmc(cg_ctx* c, double* x, const int* sidx, int B, int steps, dou
 int cg_gen_run_param_vjp(cg_ctx* c, int grid, const double* x, const int* sidx, int B, const double* w_re, const double* w_im,
                          double* partial, double* score);
 int cg_gen_run_grad_lap(cg_ctx* c, int grid, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap);
+extern "C" int cg_fisher_real_nr(cg_ctx* c, const double* S_dev, int B, int P, double* F_dev);

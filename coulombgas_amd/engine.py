@@ -602,6 +602,37 @@ class Engine:
         logp.version += 1
         return logp
 
+    def van_scores_compute_d(self, sidx_d):
+        """per-sample classical scores d log p_b / d params (flat order) for these samples; resident in the context until the
+        samples or the parameters change (cg_van_scores_compute)"""
+        key = (id(sidx_d), sidx_d.version, self._van_version)
+        if getattr(self, "_van_scores_key", None) != key:
+            self._dev_call(lib().cg_van_scores_compute, sidx_d.ptr, int(sidx_d.shape[0]))
+            self._van_scores_key = key
+            self._van_scores_B = int(sidx_d.shape[0])
+        return self._van_scores_B
+
+    def van_scores_vjp_d(self, w_d, out_d):
+        """out (count) = sum_b w[b] S_b"""
+        self._dev_call(lib().cg_van_scores_vjp, w_d.ptr, out_d.ptr)
+        out_d.version += 1
+        return out_d
+
+    def van_scores_fisher_d(self, perm=None):
+        """(count, count) S^T S / B, rows / columns in the order perm (ravel index -> flat index) when given"""
+        n = lib().cg_van_num_params(*self._van_key[0], self.dim)
+        F = self.scratch("van_fisher", (n, n))
+        p = self.asdevice(np.ascontiguousarray(perm, dtype=np.int32), "van_perm", np.int32) if perm is not None else None
+        self._dev_call(lib().cg_van_scores_fisher, p.ptr if p is not None else None, F.ptr)
+        F.version += 1
+        return F
+
+    def van_scores_get(self):
+        n = lib().cg_van_num_params(*self._van_key[0], self.dim)
+        out = self.scratch("van_scores_copy", (self._van_scores_B, n))
+        self._dev_call(lib().cg_van_scores_get, out.ptr)
+        return self.to_host(out)
+
     def van_log_prob(self, state_idx):
         s = _i32(state_idx).reshape(-1, self.n)
         out = np.empty(s.shape[0])

@@ -117,8 +117,11 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
         last_engine[0] = eng
         classical_fisher = None
         if classical_score_fn is not None:
-            cs = _ravel_batched(classical_score_fn(params_van, state_indices))
-            classical_fisher = cm.pmean_d(eng.fisher_real_d(cs))                         # :77-79
+            cs = classical_score_fn(params_van, state_indices)
+            if hasattr(cs, "fisher_d"):                       # device Transformer: the scores never leave the GPU
+                classical_fisher = cm.pmean_d(cs.fisher_d())
+            else:
+                classical_fisher = cm.pmean_d(eng.fisher_real_d(_ravel_batched(cs)))     # :77-79
         x_d = eng.asdevice(x, "x")
         s_d = eng.asdevice(state_indices, "sidx", np.int32)
         eng.scores_compute_d(x_d, s_d)                                                   # :69-71 (shared with the theta-VJP)

@@ -164,6 +164,18 @@ int cg_van_log_prob(cg_ctx* ctx, const int32_t* state_idx, int B, double* logp);
  * log_prob(params_van, state_indices) pass of src/VMC.py:34). */
 int cg_van_sample(cg_ctx* ctx, int B, uint64_t seed, uint64_t offset, const double* unif, int32_t* state_idx, double* logp);
 
+/* Per-sample classical scores S_b = d log p(state_idx_b) / d params (flat parameter order): jax.vmap(jax.grad(log_prob)) of
+ * src/sampler.py:52-65, computed by a hand-written reverse pass on the device and kept resident there (B x count doubles):
+ *   cg_van_scores_vjp    g (count) = sum_b w[b] S_b: jax.jacrev(classical_lossfn) of main.py:277 with w = F_clipped / B (and 1 / B)
+ *   cg_van_scores_fisher F (count, count) = S^T S / B: the classical Fisher matrix of src/sr.py:77-79 before its pmean; perm (count
+ *                        int32, or NULL) reorders it to the caller's parameter order, F[i][j] = <S[perm[i]] S[perm[j]]> (jax's
+ *                        ravel_pytree order differs from the flat order above)
+ *   cg_van_scores_get    the matrix itself. */
+int cg_van_scores_compute(cg_ctx* ctx, const int32_t* state_idx, int B);
+int cg_van_scores_vjp(cg_ctx* ctx, const double* w, double* g);
+int cg_van_scores_fisher(cg_ctx* ctx, const int32_t* perm, double* fisher);
+int cg_van_scores_get(cg_ctx* ctx, double* scores);
+
 /* ---- local energy and loss weights on the device (K8) ----------------------------------------------------- */
 
 /* src/VMC.py:39-58 for ONE device, before the pmean: from grad (B,n,dim,2), lap (B,2) of cg_grad_laplacian and V (B) of

@@ -890,6 +890,71 @@ def test_transformer_density_matrix_on_device():
     eng.close()
 
 
+def test_transformer_reverse_pass_on_device():
+    """jax.vmap(jax.grad(log_prob)) (src/sampler.py:52-65) and jax.jacrev of the weighted log-probability sums (main.py:277) from
+    the device's hand-written reverse pass (cg_van_scores_*): per-sample scores against torch autograd through the oracle's
+    restatement and against the host numpy backward; the weighted VJP; the classical Fisher matrix in ravel_pytree order;
+    the shipped n = 57 model (M = 149: three lane-rounds of logits, stash in HBM)."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    from coulombgas_amd.sr import ravel_pytree, _ravel_batched
+    from oracle import cg_ref as R
+    dim = 2
+    rng = np.random.default_rng(14)
+    for n, M, nl, ms, nh, hsz, B in ((5, 12, 2, 16, 4, 32, 70), (4, 10, 1, 8, 2, 16, 33), (3, 70, 3, 32, 4, 48, 20)):
+        sp = orbitals(2)[-M:] if M <= 25 else orbitals(2, 25)[:M] if M <= 81 else orbitals(2, 49)[:M]
+        eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp)
+        van = cg.Transformer(M, nl, ms, nh, hsz)
+        params = van.init(rng, sp[:n])
+        for mod in params:
+            for leaf in params[mod]:
+                params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
+        sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M, engine=eng)
+        _, hlp = cg.make_autoregressive_sampler(van, sp, n, M)
+        s_d = sampler(params, 3, B)
+        s = np.asarray(s_d)
+        sc = log_prob.grad(params, s_d)
+        S = np.asarray(sc)                                                    # (B, P), ravel_pytree order
+        Sh = _ravel_batched(hlp.grad(params, s))
+        scale = np.abs(Sh).max()
+        assert S.shape == Sh.shape and np.abs(S - Sh).max() < 1e-12 * scale, (n, M, np.abs(S - Sh).max() / scale)
+        # torch autograd through the oracle's restatement of src/autoregressive.py + src/sampler.py (first 6 samples)
+        for b in range(6):
+            tp = {m: {l: R.T(v).clone().requires_grad_(True) for l, v in params[m].items()} for m in params}
+            lp = R.autoregressive_log_prob(tp, torch.as_tensor(s[b].astype(np.int64)), R.T(sp), nl, nh)
+            lp.backward()
+            gref = ravel_pytree({m: {l: tp[m][l].grad.numpy() for l in tp[m]} for m in tp})[0]
+            assert np.abs(S[b] - gref).max() < 1e-12 * scale, (n, M, b, np.abs(S[b] - gref).max() / scale)
+        # per-leaf view
+        tree = sc.tree()
+        href = hlp.grad(params, s)
+        for mod in href:
+            for leaf in href[mod]:
+                assert tree[mod][leaf].shape == href[mod][leaf].shape
+                assert np.abs(tree[mod][leaf] - href[mod][leaf]).max() < 1e-12 * scale
+        w = rng.standard_normal(B) / B
+        gv = ravel_pytree(log_prob.vjp(params, s_d, w))[0]
+        assert np.abs(gv - w @ Sh).max() < 1e-12 * np.abs(w @ Sh).max()
+        gv2 = ravel_pytree(log_prob.vjp(params, s, w))[0]                      # host samples are uploaded
+        assert np.array_equal(gv, gv2)
+        F = eng.to_host(sc.fisher_d())
+        Fh = Sh.T @ Sh / B
+        assert np.abs(F - Fh).max() < 1e-12 * np.abs(Fh).max()
+        eng.close()
+    n = 57
+    sp49 = orbitals(2, 49)
+    pv = _load_van("shipped_n57_rs10_van.npz")
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp49)
+    van = cg.Transformer(sp49.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], engine=eng)
+    _, hlp = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0])
+    s_d = sampler(pv, 5, 40)
+    S = np.asarray(log_prob.grad(pv, s_d))
+    Sh = _ravel_batched(hlp.grad(pv, np.asarray(s_d)))
+    assert np.abs(S - Sh).max() < 1e-11 * np.abs(Sh).max(), np.abs(S - Sh).max() / np.abs(Sh).max()
+    eng.close()
+
+
 def test_freefermion_pretraining_on_device():
     """f4 (src/freefermion/pretraining.py:34-108) with the density matrix sampled and evaluated on the GPU and the classical
     Fisher matrix formed there: natural-gradient pre-training of a small Transformer lowers F = <log p / beta + E> towards the
