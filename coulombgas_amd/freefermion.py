@@ -57,8 +57,8 @@ def make_loss(log_prob, Es, beta):
 def pretrain(van, params_van, n, dim, Theta, sp_indices_twist, key, lr=1e-3, sr=True, damping=1e-3, max_norm=1e-3,
              batch=8192, epoch=5000, log=None, engine=None):
     """src/freefermion/pretraining.py:34-108.  sp_indices_twist: the reversed twisted orbital table (main.py:79-90).
-    engine: a GPU Engine for (n, dim): the sampler, the log-probabilities and the classical Fisher matrix + damped solve then run
-    on the device (the reverse pass of the Transformer stays host numpy).
+    engine: a GPU Engine for (n, dim): the sampler, the log-probabilities, the reverse pass (per-sample scores, weighted VJP) and
+    the classical Fisher matrix + damped solve then run on the device.
     Returns the trained params_van and the data.txt rows (epoch, F, F_std, E, E_std, S, S_std)."""
     if dim == 3:
         L = (4 / 3 * np.pi * n) ** (1 / 3); beta = 1 / ((4.5 * np.pi) ** (2 / 3) * Theta)

@@ -93,8 +93,12 @@ def fisher_sr(score_fn, damping, max_norm, engine=None):
     def update_fn(grads, state, params):
         params, state_indices = params
         g, unravel = ravel_pytree(grads)
-        score = _ravel_batched(score_fn(params, state_indices))
-        fisher = engine.fisher_real(score) if engine is not None and hasattr(engine, "fisher_real") else score.T.dot(score) / score.shape[0]
+        score = score_fn(params, state_indices)
+        if hasattr(score, "fisher_d"):                        # device Transformer: scores and Fisher matrix stay on the GPU
+            fisher = score.fisher_d()
+        else:
+            score = _ravel_batched(score)
+            fisher = engine.fisher_real(score) if engine is not None and hasattr(engine, "fisher_real") else score.T.dot(score) / score.shape[0]
         return unravel(_solve_and_clip(fisher, g, damping, max_norm, engine)), state
 
     return GradientTransformation(init_fn, update_fn)

@@ -890,6 +890,31 @@ def test_transformer_density_matrix_on_device():
     eng.close()
 
 
+def test_classical_fisher_and_blocked_cholesky_at_ragged_sizes():
+    """src/sr.py:36 / :38-41 at sizes that exercise every edge of the blocked kernels: 64 x 64 wave blocks of the SYRK with ragged
+    last blocks and a sliced batch, the 64-column Cholesky panels (MFMA panel solve with the inverse diagonal block, 64 x 64
+    trailing blocks), one-launch-per-block triangular solves."""
+    from coulombgas_amd.engine import Engine
+    rng = np.random.default_rng(8)
+    eng = Engine(3, 2, 2, 16, 16, box_length(3, 2), orbitals(2))
+    for B, P in ((1000, 333), (130, 64), (257, 129), (50, 500), (4099, 191)):
+        S = rng.standard_normal((B, P))
+        F = eng.fisher_real(S)
+        ref = S.T @ S / B
+        assert np.abs(F - ref).max() < 1e-13 * np.abs(ref).max() * np.sqrt(B) and np.array_equal(F, F.T), (B, P)
+    for P in (64, 65, 127, 333, 700, 1153):
+        S = rng.standard_normal((2 * P, P))
+        M = S.T @ S / (2 * P) + 1e-3 * np.eye(P)
+        Lg = eng.cholesky(M)
+        Lr = np.linalg.cholesky(M)
+        assert np.abs(np.tril(Lg) - Lr).max() < 1e-10 * np.abs(Lr).max(), P
+        rhs = rng.standard_normal(P)
+        xg = eng.spd_solve(M, rhs, 1e-3)
+        xr = np.linalg.solve(M + 1e-3 * np.eye(P), rhs)
+        assert np.abs(xg - xr).max() < 1e-10 * np.abs(xr).max(), P
+    eng.close()
+
+
 def test_transformer_reverse_pass_on_device():
     """jax.vmap(jax.grad(log_prob)) (src/sampler.py:52-65) and jax.jacrev of the weighted log-probability sums (main.py:277) from
     the device's hand-written reverse pass (cg_van_scores_*): per-sample scores against torch autograd through the oracle's

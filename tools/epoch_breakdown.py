@@ -26,7 +26,8 @@ G = cg.kpoints(2, 15); Vconst = n * rs / L * cg.Madelung(2, 10, G)
 lp0 = cg.make_logpsi(flow, sp, L); logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L); logp = cg.make_logp(lp0)
 logpsi, lgl = cg.make_logpsi_grad_laplacian(lp0, hutchinson=True, logphi=logphi, logjacdet=logjac)
 loss = cg.make_loss(samp.log_prob, logpsi, lgl, 10, G, L, rs, Vconst, 1 / 0.6)
-fishers_fn, opt = cg.hybrid_fisher_sr(None, cg.make_quantum_score(lp0), 1e-3, 1e-3)
+cscore = cg.make_classical_score(samp.log_prob) if pv is not None and "--frozen-van" not in sys.argv else None
+fishers_fn, opt = cg.hybrid_fisher_sr(cscore, cg.make_quantum_score(lp0), 1e-3, 1e-3)
 x = np.random.default_rng(0).uniform(0, L, (B, n, 2)); key = np.random.SeedSequence(1)
 if "--host-arrays" not in sys.argv:          # default: the walkers live in HBM (DeviceArray), as in coulombgas_amd.train
     from coulombgas_amd.engine import DeviceArray
@@ -39,10 +40,19 @@ for ep in range(4):
     key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, pv, logp, x, p0, 50, 0.1, L))
     data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(pv, p0, sidx, x, key))
     g, s = tm("quantum grad (scores + VJP)", lambda: qloss.grad(p0, reduce=True))
+    gvan = None
+    if cscore is not None:                   # main.py:277: jax.jacrev(classical_lossfn)
+        def cgrad():
+            closs(pv)
+            gv = samp.log_prob.vjp(pv, sidx, closs.weights); sv = samp.log_prob.vjp(pv, sidx, closs.score_weights)
+            return {m: {l: gv[m][l] - data["F_mean"] * sv[m][l] for l in gv[m]} for m in gv}
+        gvan = tm("classical grad (scores + VJPs)", cgrad)
     f = tm("fishers_fn", lambda: fishers_fn(pv, p0, sidx, x))
     gf = {k: {l: g[k][l] - data["E_mean"] * s[k][l] for l in g[k]} for k in g}
-    (uv, uf), _ = tm("SR solve+clip", lambda: opt.update((None, gf), None, f))
+    (uv, uf), _ = tm("SR solve+clip", lambda: opt.update((gvan, gf), None, f))
     p0 = tm("apply", lambda: cg.apply_updates(p0, uf))
+    if uv is not None:
+        pv = tm("apply", lambda: cg.apply_updates(pv, uv))
 for k, v in T.items():
     print("%-30s %7.1f ms" % (k, v / 3 * 1e3))
 print("%-30s %7.1f ms" % ("total", sum(T.values()) / 3 * 1e3))
