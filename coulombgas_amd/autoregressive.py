@@ -229,19 +229,23 @@ class DeviceScores:
         return a if dtype is None else a.astype(dtype)
 
 
-def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None):
+def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None, host=False):
     """src/sampler.py:4-50 with a leading batch axis built in (the reference vmaps).  sampler(params, key, batch) ->
     (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,).
     engine (or sampler.attach(engine) later; coulombgas_amd.train does it): a GPU Engine of the same (n, dim) -- the sampler
     and the log-probability then run on the device (cg_van_sample / cg_van_log_prob: one wave per sample, key / value cache
     in LDS) and hand DeviceArrays to the hot path, and the gradients (log_prob.grad -> DeviceScores, log_prob.vjp) come from
-    the device's reverse pass (cg_van_scores_*); without one this numpy implementation runs on the host."""
+    the device's reverse pass (cg_van_scores_*).  Calling the closures with no engine attached raises: the numpy
+    restatement below is the checker of the device kernels (tests) and runs only when asked for with host=True."""
     sp_indices = np.asarray(sp_indices, dtype=np.float64)
     base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
     dev = {"engine": engine}
 
     def _dev_engine(params):
         eng = dev["engine"]
+        if eng is None and not host:
+            raise RuntimeError("autoregressive density matrix: no GPU engine attached (pass engine= / call .attach(engine); "
+                               "coulombgas_amd.train attaches its own).  host=True selects the numpy restatement used by the tests.")
         if eng is not None:
             eng.van_set_params((num_states, network.num_layers, network.model_size, network.num_heads, network.hidden_size),
                                sp_indices, flat_params(network, params, sp_indices.shape[1]))

@@ -10,7 +10,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 L = box_length(n, 2); sp = orbitals(2, 25)
 flow = cg.FermiNet(2, 16, 16, L); pf = flow.init(1, np.zeros((n, 2)))
 van = cg.Transformer(sp.shape[0], 2, 16, 4, 32); pv = van.init(2, sp[-n:])
-samp, logp = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0])
+samp, logp = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], host=True)
 t = [time.perf_counter()]
 def log(row):
     t.append(time.perf_counter()); print(row, " | %.0f ms" % ((t[-1] - t[-2]) * 1e3), flush=True)
