@@ -32,6 +32,7 @@
 struct CgFastLds {
     int sh, ch, m0, s1, sg1, m1, gbar, cb, sg2, s2, z, U, V, Bm, Up, G, J, Dm, perm, wt, lus, total;
     int wave_lu;      // 1: both determinants by the wave-level register LU (N <= 32, n <= 16, Dm not on J)
+    int dual;         // 1: (large n, sampler layout) the Slater matrix has LDS of its own while J is factored: both LUs run concurrently
 };
 
 template <int D, int HS, int HT>
@@ -1029,12 +1030,23 @@ struct CgFast {
             // larger sizes: workgroup-wide blocked LUs (4-column panels on wave 0, MFMA trailing updates on every wave).
             // The Slater matrix may share J's LDS (o.Dm == o.J), so it is formed after the real factorisation.
             double* res = (double*)perm;
-            half_logdetJ = 0.5 * cg_blocked_lu_logabsdet(b, lds + o.J, n * D, n * D, res);
-            CG_STAMP(12)                               // (diagnostic builds, this branch: 12 = real LU, 13 = Slater matrix, 14 = complex LU)
-            slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
-            CG_STAMP(13)
-            cg_blocked_lu_logdet_complex(b, lds + o.Dm, n, n, res, la, ar);
-            CG_STAMP(14)
+            if (o.dual && b.nthr >= 192 && b.nthr <= 1024 && n * D <= 128 && n <= 64) {
+                // both matrices have LDS of their own: the Slater matrix is formed first and the two LUs run concurrently
+                slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
+                CG_STAMP(12)                           // (diagnostic builds, this branch: 12 = Slater matrix, 13 = both LUs)
+                double lr;
+                cg_blocked_lu_dual(b, lds + o.J, n * D, n * D, lds + o.Dm, n, n, res, lr, la, ar);
+                half_logdetJ = 0.5 * lr;
+                CG_STAMP(13)
+                CG_STAMP(14)
+            } else {
+                half_logdetJ = 0.5 * cg_blocked_lu_logabsdet(b, lds + o.J, n * D, n * D, res);
+                CG_STAMP(12)                           // (diagnostic builds, this branch: 12 = real LU, 13 = Slater matrix, 14 = complex LU)
+                slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
+                CG_STAMP(13)
+                cg_blocked_lu_logdet_complex(b, lds + o.Dm, n, n, res, la, ar);
+                CG_STAMP(14)
+            }
         }
 #else
         {
@@ -1059,11 +1071,23 @@ struct CgFast {
 static CG_HD CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, bool mfma = false) {
     CgFastLds o; int P = 2 * D + 1, t = 0;
     auto take = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
-    o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
-    o.sg1 = take(n * HS); o.sg2 = take(n * HS);
-    // results of the wave-level LUs (3 doubles) or, on the LDS LU path, its argmax scratch (>= 40 doubles)
-    o.perm = take((n * D <= 32 && n <= 16) ? 4 : 40);
-    o.wt = take(HT * (P + 1) + HS * D);                 // two-particle layer weights [h][bias, P weights], then Wf (HS x D)
+    const bool small = n * D <= 32 && n <= 16;
+    o.dual = 0;
+    int dead0 = 0;                                      // (large n, sampler) start of what is dead once J is assembled
+    if (alias && !small) {
+        // large n: everything but z and the LU scratch is dead after the Jacobian assembly; kept contiguous so that the
+        // Slater matrix fits over it (n = 57: 6626 doubles against 2 n^2 = 6498) and is factored WHILE J is factored.
+        o.z = take(n * D); o.perm = take(112);           // CG_LU_DUAL_DOUBLES: flags + every pivot of both LUs
+        dead0 = t;
+        o.sh = take(n * D); o.ch = take(n * D); o.sg1 = take(n * HS); o.sg2 = take(n * HS);
+        o.wt = take(HT * (P + 1) + HS * D);
+    } else {
+        o.sh = take(n * D); o.ch = take(n * D); o.z = take(n * D);
+        o.sg1 = take(n * HS); o.sg2 = take(n * HS);
+        // results of the wave-level LUs (3 doubles) or, on the LDS LU path, its argmax scratch (>= 40 doubles)
+        o.perm = take(small ? 4 : 40);
+        o.wt = take(HT * (P + 1) + HS * D);             // two-particle layer weights [h][bias, P weights], then Wf (HS x D)
+    }
     if (!alias) {
         o.m0 = take(n * P); o.s1 = take(n * HS); o.m1 = take(n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take(n * HS);
         o.U = take(n * D * HS); o.V = take(n * (HT * D + 2)); o.Bm = take(n * (HS * D + 2)); o.Up = take(n * D * P); o.G = take(n * (HS * D + 2));
@@ -1087,8 +1111,11 @@ static CG_HD CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, 
     o.J = take(n * D * n * D);
     o.U = o.J;                                          // n*D*HS <= (n*D)^2 whenever HS <= n*D
     if (n * D * HS > n * D * n * D) { o.U = take(n * D * HS); }
+    const int end_dead = end_primal > end_jac ? end_primal : end_jac;
     if (end_jac - base >= 2 * n * n) o.Dm = base;       // Slater matrix over the dead per-particle factors
-    else o.Dm = o.J;                                    // large n: over J after its LU (2 n^2 <= (n D)^2)
+    else if (!small && end_dead - dead0 >= 2 * n * n) o.Dm = dead0;   // ... over everything that is dead after the assembly
+    else o.Dm = o.J;                                    // over J after its LU (2 n^2 <= (n D)^2)
+    o.dual = (!small && o.Dm != o.J) ? 1 : 0;
     // pivot-row scratch of the wave-level LUs (2 x 32 doubles): behind the Slater matrix, still inside the dead factors
     o.lus = base + ((2 * n * n + 1) & ~1);
     o.wave_lu = (n * D <= 32 && n <= 16 && o.Dm != o.J && o.lus + 64 <= end_jac) ? 1 : 0;

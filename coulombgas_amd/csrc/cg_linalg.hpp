@@ -797,18 +797,78 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex_lds(const CgBlk& b,
 #define CG_LU_PW 8
 struct CgLuPanelReal {
     // factor panel starting at column k0 (kb columns) -> L in place, pivots to pv; returns through `prod`
-    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgScaledProd& prod) {
+    // sk0 >= 0: the rows of this panel's columns have not yet received panel (sk0, skb) -- its U12 is in place (column()) --
+    // and get A22 -= L21 U12 here, in the registers they are factored in (L21: 8 contiguous doubles of the lane's row, U12: 64
+    // broadcast reads); the MFMA tile route cost an LDS round trip of the strip plus the latency of seven dependent trips.
+    // FULL: kb == PW known at compile time (every panel but the last): no per-column width tests in the unrolled chain
+    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgScaledProd& prod,
+                                                  int sk0 = -1, int skb = 0) {
+        double lrow[CG_LU_PW]; int piv[CG_LU_PW];
+        factor_keep(A, N, lda, k0, kb, lane, pv, prod, sk0, skb, lrow, piv);
+    }
+    // lrow / piv: on return lane j < kb holds row k0 + j of the factored panel (L11 below its diagonal) and piv[j] the pivot
+    // rows as wave-uniform values: column_reg() takes both from registers instead of 36 LDS reads on the pivot chain
+    static __device__ __forceinline__ void factor_keep(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgScaledProd& prod,
+                                                       int sk0, int skb, double (&lrow)[CG_LU_PW], int (&piv)[CG_LU_PW]) {
+        if (kb == CG_LU_PW) factor_t<true>(A, N, lda, k0, CG_LU_PW, lane, pv, prod, sk0, skb, lrow, piv);
+        else factor_t<false>(A, N, lda, k0, kb, lane, pv, prod, sk0, skb, lrow, piv);
+    }
+    template <bool FULL>
+    static __device__ __forceinline__ void factor_t(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgScaledProd& prod,
+                                                    int sk0, int skb, double (&lrow)[CG_LU_PW], int (&piv)[CG_LU_PW]) {
         constexpr int PW = CG_LU_PW;
         const int r0 = k0 + lane, r1 = r0 + 64;
         double a0[PW], a1[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            a0[j] = (r0 < N && j < kb) ? A[r0 * lda + k0 + j] : 0.0;
-            a1[j] = (r1 < N && j < kb) ? A[r1 * lda + k0 + j] : 0.0;
+            a0[j] = (r0 < N && (FULL || j < kb)) ? A[r0 * lda + k0 + j] : 0.0;
+            a1[j] = (r1 < N && (FULL || j < kb)) ? A[r1 * lda + k0 + j] : 0.0;
+        }
+        if (sk0 >= 0) {
+            const bool two = N > k0 + 64;                                 // any second row of a lane (wave-uniform)
+            if (FULL && skb == PW && (lda & 1) == 0) {                // full panels: unconditional, vector LDS reads
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                double l0[PW], l1[PW];
+                const d2_t* p0 = (const d2_t*)(A + (r0 < N ? r0 : N - 1) * lda + sk0);
+                const d2_t* p1 = (const d2_t*)(A + (r1 < N ? r1 : N - 1) * lda + sk0);
+#pragma unroll
+                for (int q = 0; q < PW / 2; ++q) {
+                    const d2_t v0 = p0[q]; l0[2 * q] = v0[0]; l0[2 * q + 1] = v0[1];
+                    if (two) { const d2_t v1 = p1[q]; l1[2 * q] = v1[0]; l1[2 * q + 1] = v1[1]; } else { l1[2 * q] = 0.0; l1[2 * q + 1] = 0.0; }
+                }
+#pragma unroll
+                for (int q = 0; q < PW; ++q) {
+                    const d2_t* pu = (const d2_t*)(A + (sk0 + q) * lda + k0);   // wave-uniform address: LDS broadcast
+#pragma unroll
+                    for (int j = 0; j < PW / 2; ++j) {
+                        const d2_t u = pu[j];
+                        a0[2 * j] = fma(-l0[q], u[0], a0[2 * j]); a0[2 * j + 1] = fma(-l0[q], u[1], a0[2 * j + 1]);
+                        if (two) { a1[2 * j] = fma(-l1[q], u[0], a1[2 * j]); a1[2 * j + 1] = fma(-l1[q], u[1], a1[2 * j + 1]); }
+                    }
+                }
+            } else {
+                double l0[PW], l1[PW];
+#pragma unroll
+                for (int q = 0; q < PW; ++q) {
+                    l0[q] = (r0 < N && q < skb) ? A[r0 * lda + sk0 + q] : 0.0;
+                    l1[q] = (r1 < N && q < skb) ? A[r1 * lda + sk0 + q] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < PW; ++q) {
+                    if (q < skb) {
+#pragma unroll
+                        for (int j = 0; j < PW; ++j) {
+                            const double u = j < kb ? A[(sk0 + q) * lda + k0 + j] : 0.0;
+                            a0[j] = fma(-l0[q], u, a0[j]);
+                            a1[j] = fma(-l1[q], u, a1[j]);
+                        }
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            if (j < kb) {
+            if (FULL || j < kb) {
                 const int k = k0 + j;
                 // threshold pivoting (as in the wave-level LUs): row k serves unless some candidate is more than 4x larger
                 // (growth bounded by 5 per step); only then the full search and the row exchange run.  For J = I + small
@@ -827,20 +887,21 @@ struct CgLuPanelReal {
                 }
                 const int lp = (p - k0) & 63, sp = (p - k0) >> 6;         // wave-uniform
                 double rp[PW];
-#pragma unroll
-                for (int jj = 0; jj < PW; ++jj) rp[jj] = cg_readlane_f64(sp ? a1[jj] : a0[jj], lp);
                 if (p != k) {                                             // exchange rows k and p inside the panel
 #pragma unroll
                     for (int jj = 0; jj < PW; ++jj) {
-                        const double rk = cg_readlane_f64(a0[jj], j);
-                        if (lane == j) a0[jj] = rp[jj];
+                        const double rk = cg_readlane_f64(a0[jj], j), rq = cg_readlane_f64(sp ? a1[jj] : a0[jj], lp);
+                        if (lane == j) a0[jj] = rq;
                         if (lane == lp) { if (sp) a1[jj] = rk; else a0[jj] = rk; }
                     }
                 }
+#pragma unroll
+                for (int jj = j; jj < PW; ++jj) rp[jj] = cg_readlane_f64(a0[jj], j);   // the pivot row now sits in lane j
                 if (lane == 0) pv[j] = p;
-                const double piv = rp[j];
-                prod.mul(piv);
-                const double rinv = cg_fast_rcp1(piv);                     // (the determinant uses the pivots themselves)
+                piv[j] = p;
+                const double pvt = rp[j];
+                prod.mul(pvt);
+                const double rinv = cg_fast_rcp1(pvt);                     // (the determinant uses the pivots themselves)
                 if (r0 > k && r0 < N) {
                     const double l = a0[j] * rinv; a0[j] = l;
 #pragma unroll
@@ -855,10 +916,39 @@ struct CgLuPanelReal {
         }
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            if (j < kb) {
+            if (FULL || j < kb) {
                 if (r0 < N) A[r0 * lda + k0 + j] = a0[j];
                 if (r1 < N) A[r1 * lda + k0 + j] = a1[j];
+            } else piv[j] = k0 + j;
+            lrow[j] = a0[j];
+        }
+    }
+    // column() for the pivot chain: L11 and the pivots of the (full) panel come from the registers factor_keep() left them in
+    static __device__ __forceinline__ void column_reg(double* A, int lda, int k0, const double (&lrow)[CG_LU_PW], const int (&piv)[CG_LU_PW],
+                                                      int c, bool on) {
+        constexpr int PW = CG_LU_PW;
+        double u[PW];
+#pragma unroll
+        for (int r = 0; r < PW; ++r) u[r] = on ? A[(k0 + r) * lda + c] : 0.0;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const int p = piv[j];                                          // wave-uniform: scalar branch, almost never taken
+            if (p != k0 + j) {
+                if (p < k0 + PW) {
+#pragma unroll
+                    for (int q = j + 1; q < PW; ++q) if (p - k0 == q) { const double t = u[j]; u[j] = u[q]; u[q] = t; }
+                } else if (on) {
+                    const double t = A[p * lda + c]; A[p * lda + c] = u[j]; u[j] = t;
+                }
             }
+        }
+#pragma unroll
+        for (int r = 1; r < PW; ++r)
+#pragma unroll
+            for (int q = 0; q < r; ++q) u[r] = fma(-cg_readlane_f64(lrow[q], r), u[q], u[r]);
+        if (on) {
+#pragma unroll
+            for (int r = 0; r < PW; ++r) A[(k0 + r) * lda + c] = u[r];
         }
     }
     // deferred row exchanges of panel (k0, kb, pv) applied to column c, then U12[:, c] = L11^-1 A12[:, c]
@@ -943,10 +1033,8 @@ __device__ __forceinline__ double cg_blocked_lu_logabsdet(const CgBlk& b, double
                 if (lane < nb) CgLuPanelReal::column(A, lda, k0, kb, pv, m0 + lane);
                 asm volatile("" ::: "memory");             // (LDS executes one wave's accesses in order)
                 CG_STAMP(16)
-                CgLuPanelReal::tiles(A, N, lda, k0, kb, m0, m0, m0 + nb, lane);
-                asm volatile("" ::: "memory");
                 CG_STAMP(17)
-                CgLuPanelReal::factor(A, N, lda, m0, nb, lane, pivs + ((k + 1) & 1) * PW, prod);
+                CgLuPanelReal::factor(A, N, lda, m0, nb, lane, pivs + ((k + 1) & 1) * PW, prod, k0, kb);   // strip update in registers
                 CG_STAMP_END(18)
             }
         } else {
@@ -971,19 +1059,44 @@ __device__ __forceinline__ double cg_blocked_lu_logabsdet(const CgBlk& b, double
 }
 
 struct CgLuPanelCplx {
-    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgCplx& pm, int& pe) {
+    // sk0 >= 0: the rows of this panel's columns get A22 -= L21 U12 of panel (sk0, PW) here, in registers (see the real version)
+    static __device__ __forceinline__ void factor(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgCplx& pm, int& pe, int sk0 = -1) {
+        if (kb == CG_LU_PW) factor_t<true>(A, N, lda, k0, CG_LU_PW, lane, pv, pm, pe, sk0);
+        else factor_t<false>(A, N, lda, k0, kb, lane, pv, pm, pe, sk0);
+    }
+    template <bool FULL>
+    static __device__ __forceinline__ void factor_t(double* A, int N, int lda, int k0, int kb, int lane, int* pv, CgCplx& pm, int& pe, int sk0) {
         constexpr int PW = CG_LU_PW;
         const int r0 = k0 + lane;
         double ar_[PW], ai_[PW];
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const bool ok = r0 < N && j < kb;
+            const bool ok = r0 < N && (FULL || j < kb);
             ar_[j] = ok ? A[2 * (r0 * lda + k0 + j)] : 0.0;
             ai_[j] = ok ? A[2 * (r0 * lda + k0 + j) + 1] : 0.0;
         }
+        if (sk0 >= 0) {                                                   // strip update by the full panel (sk0, PW)
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t* pl = (const d2_t*)(A + 2 * ((r0 < N ? r0 : N - 1) * lda + sk0));
+            d2_t l[PW];
+#pragma unroll
+            for (int q = 0; q < PW; ++q) l[q] = pl[q];
+#pragma unroll
+            for (int q = 0; q < PW; ++q) {
+                const d2_t* pu = (const d2_t*)(A + 2 * ((sk0 + q) * lda + k0));   // wave-uniform address: LDS broadcast
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    if (FULL || j < kb) {
+                        const d2_t u = pu[j];
+                        ar_[j] = ar_[j] - (l[q][0] * u[0] - l[q][1] * u[1]);
+                        ai_[j] = ai_[j] - (l[q][0] * u[1] + l[q][1] * u[0]);
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            if (j < kb) {
+            if (FULL || j < kb) {
                 const int k = k0 + j;
                 // threshold pivoting: row k serves unless some candidate is more than 4x larger in modulus
                 const double m2 = (r0 >= k && r0 < N) ? ar_[j] * ar_[j] + ai_[j] * ai_[j] : 0.0;
@@ -997,16 +1110,17 @@ struct CgLuPanelCplx {
                 }
                 const int p = k0 + lp;
                 double rpr[PW], rpi[PW];
-#pragma unroll
-                for (int jj = 0; jj < PW; ++jj) { rpr[jj] = cg_readlane_f64(ar_[jj], lp); rpi[jj] = cg_readlane_f64(ai_[jj], lp); }
                 if (p != k) {
 #pragma unroll
                     for (int jj = 0; jj < PW; ++jj) {
                         const double rkr = cg_readlane_f64(ar_[jj], j), rki = cg_readlane_f64(ai_[jj], j);
-                        if (lane == j) { ar_[jj] = rpr[jj]; ai_[jj] = rpi[jj]; }
+                        const double rqr = cg_readlane_f64(ar_[jj], lp), rqi = cg_readlane_f64(ai_[jj], lp);
+                        if (lane == j) { ar_[jj] = rqr; ai_[jj] = rqi; }
                         if (lane == lp) { ar_[jj] = rkr; ai_[jj] = rki; }
                     }
                 }
+#pragma unroll
+                for (int jj = j; jj < PW; ++jj) { rpr[jj] = cg_readlane_f64(ar_[jj], j); rpi[jj] = cg_readlane_f64(ai_[jj], j); }   // pivot row: lane j
                 if (lane == 0) pv[j] = p;
                 const CgCplx piv = {rpr[j], rpi[j]};
                 pm = cmul(pm, piv);
@@ -1028,7 +1142,7 @@ struct CgLuPanelCplx {
         }
 #pragma unroll
         for (int j = 0; j < PW; ++j)
-            if (j < kb && r0 < N) { A[2 * (r0 * lda + k0 + j)] = ar_[j]; A[2 * (r0 * lda + k0 + j) + 1] = ai_[j]; }
+            if ((FULL || j < kb) && r0 < N) { A[2 * (r0 * lda + k0 + j)] = ar_[j]; A[2 * (r0 * lda + k0 + j) + 1] = ai_[j]; }
     }
     static __device__ __forceinline__ void column(double* A, int lda, int k0, int kb, const int* pv, int c) {
         constexpr int PW = CG_LU_PW;
@@ -1144,6 +1258,130 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, dou
     }
     b.sync();
     logabs = res[0]; arg = res[1];
+    b.sync();
+}
+// ---- both determinants of log Psi at once (large n) --------------------------------------------------------------------
+// log|det J| (real N x N) and log det D (complex n x n) are independent, and each blocked LU is bound by the sequential pivot
+// chain of its panel wave while the other waves wait.  With both matrices in LDS (CgFastLds::dual) the two chains run
+// CONCURRENTLY and DECOUPLED from the trailing updates:
+//   wave 0 : the real panels.    Step k: panel k applied to the columns of panel k + 1 (U12 + the strip in registers), panel
+//            k + 1 factored, its L and pivots published (flag pub_r = k + 2).
+//   wave 1 : the complex panels, likewise (pub_c).
+//   waves 2.. : helpers.  Each owns absolute 16-column blocks of both matrices (block j -> helper (j - 1) mod nh) and applies
+//            the published panels to them in order (deferred exchanges + U12 per column, then the MFMA row tiles), counting
+//            per block (app[j] = panels applied).  A chain wave waits only for the block that holds its next panel
+//            (app[(k + 1) >> 1] >= k); a helper takes whichever of its next real / complex task has its panel published.
+//   No workgroup barrier inside: flags in LDS with release / acquire at workgroup scope.  Every spin is bounded (a broken
+//   dependency would give wrong numbers, never a hung GPU).  The arithmetic on each matrix is that of the sequential drivers
+//   in the same order: bitwise identical results.
+// res: CG_LU_DUAL_DOUBLES doubles of LDS.
+#define CG_LU_DUAL_DOUBLES 112
+__device__ __forceinline__ int cg_flag_load(const int* f) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void cg_flag_store(int* f, int v, int lane) {
+    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void cg_flag_wait(const int* f, int need) {
+    for (int spin = 0; spin < (1 << 22) && cg_flag_load(f) < need; ++spin) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, int N, int lda, double* C, int n, int ldc, double* res,
+                                                   double& logabs_real, double& logabs_c, double& arg_c) {
+    const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
+    constexpr int PW = CG_LU_PW;
+    int* fl = (int*)(res + 4);
+    int* pub_r = fl;       int* pub_c = fl + 1;           // panels published
+    int* app_r = fl + 2;   int* app_c = fl + 10;          // [8], [4]: panels applied to absolute block j
+    int* pivr = fl + 14;   int* pivc = fl + 14 + 128;     // pivots of every panel (helpers may lag several panels behind)
+    const int npr = (N + PW - 1) / PW, npc = (n + PW - 1) / PW;
+    for (int e = b.tid; e < 14; e += b.nthr) fl[e] = 0;
+    b.sync();
+    if (wave == 0) {
+        CG_STAMP_START(16)
+        CgScaledProd prod; prod.init();
+        double lrow[PW]; int piv[PW];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) { lrow[j] = 0.0; piv[j] = 0; }
+        for (int k = -1; k + 1 < npr; ++k) {               // k = -1: panel 0 itself (one call site of the panel code)
+            const int k0 = k * PW, m0 = k0 + PW, nb = N - m0 < PW ? N - m0 : PW;
+            if (k > 0) {
+                CG_STAMP_START(18)
+                cg_flag_wait(app_r + ((k + 1) >> 1), k);
+                CG_STAMP_END(18)
+            }
+            if (k >= 0) CgLuPanelReal::column_reg(A, lda, k0, lrow, piv, m0 + lane, lane < nb);
+            asm volatile("" ::: "memory");                 // (LDS executes one wave's accesses in order)
+            CgLuPanelReal::factor_keep(A, N, lda, m0, nb, lane, pivr + m0, prod, k >= 0 ? k0 : -1, PW, lrow, piv);
+            cg_flag_store(pub_r, k + 2, lane);
+        }
+        if (lane == 0) res[0] = prod.logabs(true);
+        CG_STAMP_END(16)
+    } else if (wave == 1) {
+        CG_STAMP_START(17)
+        CgCplx pm = {1.0, 0.0}; int pe = 0;
+        for (int k = -1; k + 1 < npc; ++k) {
+            const int k0 = k * PW, m0 = k0 + PW, nb = n - m0 < PW ? n - m0 : PW;
+            if (k > 0) cg_flag_wait(app_c + ((k + 1) >> 1), k);
+            if (k >= 0 && lane < nb) CgLuPanelCplx::column(C, ldc, k0, PW, pivc + k0, m0 + lane);
+            asm volatile("" ::: "memory");
+            CgLuPanelCplx::factor(C, n, ldc, m0, nb, lane, pivc + m0, pm, pe, k >= 0 ? k0 : -1);
+            cg_flag_store(pub_c, k + 2, lane);
+        }
+        if (lane == 0) {
+            res[1] = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+            res[2] = cg_atan2_ool(pm.im, pm.re);
+        }
+        CG_STAMP_END(17)
+    } else {
+        const int nh = nw - 2, hidx = wave - 2;
+        const int nbr = (N + 15) >> 4, nbc = (n + 15) >> 4;
+        const int hc = (hidx + nbr - 1) % nh;              // the complex blocks start where the real ones stop: even spread
+        // next task of each kind: panel q applied to owned block j (blocks j >= (q + 2) >> 1 still have columns right of panel q + 1)
+        auto first_block = [&](int q, int h) { const int jm = (q + 2) >> 1; int j = 1 + h; if (j < jm) j += ((jm - j + nh - 1) / nh) * nh; return j; };
+        int qr = 0, jr = first_block(0, hidx), qc = 0, jc = first_block(0, hc);
+        while (qr + 1 < npr && jr >= nbr) { ++qr; jr = first_block(qr, hidx); }
+        while (qc + 1 < npc && jc >= nbc) { ++qc; jc = first_block(qc, hc); }
+        int idle = 0;
+        while ((qr + 1 < npr || qc + 1 < npc) && idle < (1 << 22)) {
+            bool did = false;
+            // a task is urgent when its block holds the chain's next panel (the chain waits for exactly that one):
+            // urgent real > urgent complex > complex > real
+            const bool rr = qr + 1 < npr && cg_flag_load(pub_r) > qr, rc = qc + 1 < npc && cg_flag_load(pub_c) > qc;
+            const bool ur = rr && jr == ((qr + 2) >> 1);
+            if (rc && !ur) {
+                CG_STAMP_START(19)
+                const int k0 = qc * PW, m0 = k0 + PW;
+                const int c0 = 16 * jc > m0 + PW ? 16 * jc : m0 + PW, cend = 16 * jc + 16 < n ? 16 * jc + 16 : n;
+                if (c0 < cend) {
+                    if (lane < cend - c0) CgLuPanelCplx::column(C, ldc, k0, PW, pivc + k0, c0 + lane);
+                    asm volatile("" ::: "memory");
+                    CgLuPanelCplx::tiles(C, n, ldc, k0, PW, m0, c0, cend, lane);
+                }
+                cg_flag_store(app_c + jc, qc + 1, lane);
+                jc += nh;
+                while (qc + 1 < npc && jc >= nbc) { ++qc; jc = first_block(qc, hc); }
+                did = true;
+                CG_STAMP_END(19)
+            } else if (rr) {
+                CG_STAMP_START(19)
+                const int k0 = qr * PW, m0 = k0 + PW;
+                const int c0 = 16 * jr > m0 + PW ? 16 * jr : m0 + PW, cend = 16 * jr + 16 < N ? 16 * jr + 16 : N;
+                if (c0 < cend) {
+                    if (lane < cend - c0) CgLuPanelReal::column(A, lda, k0, PW, pivr + k0, c0 + lane);
+                    asm volatile("" ::: "memory");
+                    CgLuPanelReal::tiles(A, N, lda, k0, PW, m0, c0, cend, lane);
+                }
+                cg_flag_store(app_r + jr, qr + 1, lane);
+                jr += nh;
+                while (qr + 1 < npr && jr >= nbr) { ++qr; jr = first_block(qr, hidx); }
+                did = true;
+                CG_STAMP_END(19)
+            }
+            if (!did) { ++idle; __builtin_amdgcn_s_sleep(1); }
+        }
+    }
+    b.sync();
+    logabs_real = res[0]; logabs_c = res[1]; arg_c = res[2];
     b.sync();
 }
 #endif

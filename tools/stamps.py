@@ -11,8 +11,8 @@ from coulombgas_amd import _lib
 
 NAMES = ["proposal+rng", "sincos", "primal pairs", "primal dense", "wt staging", "factors U,Bm", "G pass", "Up", "B.G",
          "factors V", "jacobian pairs", "diag blocks", "slater matrix", "real LU", "complex LU", "accept",
-         "LU wave0: strip columns", "LU wave0: strip tiles", "LU wave0: panel", "LU other waves: columns+tiles"]
-# (n > 16: 12 = real LU, 13 = Slater matrix, 14 = complex LU; 16-19: inside the real blocked LU, already counted in 12)
+         "dual LU: real chain (wave 0)", "dual LU: complex chain (wave 1)", "dual LU: real chain waiting", "dual LU: helpers (all waves summed)"]
+# (n > 16, both matrices in LDS: 12 = Slater matrix, 13 = both LUs (concurrent), 14 = 0; 16-19: inside the dual LU, already counted in 12; 16 / 17 are one wave each)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 Emax = {13: 25, 29: 25, 57: 49}[n]
