@@ -1267,15 +1267,15 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, dou
 //   wave 0 : the real panels.    Step k: panel k applied to the columns of panel k + 1 (U12 + the strip in registers), panel
 //            k + 1 factored, its L and pivots published (flag pub_r = k + 2).
 //   wave 1 : the complex panels, likewise (pub_c).
-//   waves 2.. : helpers.  Each owns absolute 16-column blocks of both matrices (block j -> helper (j - 1) mod nh) and applies
-//            the published panels to them in order (deferred exchanges + U12 per column, then the MFMA row tiles), counting
-//            per block (app[j] = panels applied).  A chain wave waits only for the block that holds its next panel
-//            (app[(k + 1) >> 1] >= k); a helper takes whichever of its next real / complex task has its panel published.
+//   waves 2.. : helpers.  A task = one published panel applied to one absolute 16-column block of one matrix (deferred
+//            exchanges + U12 per column, then the MFMA row tiles); per block the panels go in order (claim[j] = next panel,
+//            taken by compare-and-swap; app[j] = panels applied).  A chain wave waits only for the block that holds its next
+//            panel (app[(k + 1) >> 1] >= k); a free helper takes that urgent task first, whoever applied the previous panel.
 //   No workgroup barrier inside: flags in LDS with release / acquire at workgroup scope.  Every spin is bounded (a broken
 //   dependency would give wrong numbers, never a hung GPU).  The arithmetic on each matrix is that of the sequential drivers
 //   in the same order: bitwise identical results.
 // res: CG_LU_DUAL_DOUBLES doubles of LDS.
-#define CG_LU_DUAL_DOUBLES 112
+#define CG_LU_DUAL_DOUBLES 116
 __device__ __forceinline__ int cg_flag_load(const int* f) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
@@ -1291,10 +1291,11 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
     constexpr int PW = CG_LU_PW;
     int* fl = (int*)(res + 4);
     int* pub_r = fl;       int* pub_c = fl + 1;           // panels published
-    int* app_r = fl + 2;   int* app_c = fl + 10;          // [8], [4]: panels applied to absolute block j
-    int* pivr = fl + 14;   int* pivc = fl + 14 + 128;     // pivots of every panel (helpers may lag several panels behind)
+    int* claim_r = fl + 2;                                // [8] real + [4] complex: next panel to apply to absolute block j
+    int* app_r = fl + 14;  int* app_c = fl + 22;          // [8], [4]: panels applied to absolute block j
+    int* pivr = fl + 26;   int* pivc = fl + 26 + 128;     // pivots of every panel (helpers may lag several panels behind)
     const int npr = (N + PW - 1) / PW, npc = (n + PW - 1) / PW;
-    for (int e = b.tid; e < 14; e += b.nthr) fl[e] = 0;
+    for (int e = b.tid; e < 26; e += b.nthr) fl[e] = 0;
     b.sync();
     if (wave == 0) {
         CG_STAMP_START(16)
@@ -1333,51 +1334,49 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
         }
         CG_STAMP_END(17)
     } else {
-        const int nh = nw - 2, hidx = wave - 2;
+        // helpers: lane l < 8 watches real block l, lanes 8..11 complex block l - 8; one ballot picks the task
         const int nbr = (N + 15) >> 4, nbc = (n + 15) >> 4;
-        const int hc = (hidx + nbr - 1) % nh;              // the complex blocks start where the real ones stop: even spread
-        // next task of each kind: panel q applied to owned block j (blocks j >= (q + 2) >> 1 still have columns right of panel q + 1)
-        auto first_block = [&](int q, int h) { const int jm = (q + 2) >> 1; int j = 1 + h; if (j < jm) j += ((jm - j + nh - 1) / nh) * nh; return j; };
-        int qr = 0, jr = first_block(0, hidx), qc = 0, jc = first_block(0, hc);
-        while (qr + 1 < npr && jr >= nbr) { ++qr; jr = first_block(qr, hidx); }
-        while (qc + 1 < npc && jc >= nbc) { ++qc; jc = first_block(qc, hc); }
+        const bool isr = lane < 8, mine = isr ? lane < nbr : (lane < 12 && lane - 8 < nbc);
+        const int j = isr ? lane : lane - 8;
+        const int limit = !mine ? 0 : (isr ? (2 * j < npr - 1 ? 2 * j : npr - 1) : (2 * j < npc - 1 ? 2 * j : npc - 1));   // panels this block receives
         int idle = 0;
-        while ((qr + 1 < npr || qc + 1 < npc) && idle < (1 << 22)) {
-            bool did = false;
-            // a task is urgent when its block holds the chain's next panel (the chain waits for exactly that one):
-            // urgent real > urgent complex > complex > real
-            const bool rr = qr + 1 < npr && cg_flag_load(pub_r) > qr, rc = qc + 1 < npc && cg_flag_load(pub_c) > qc;
-            const bool ur = rr && jr == ((qr + 2) >> 1);
-            if (rc && !ur) {
-                CG_STAMP_START(19)
-                const int k0 = qc * PW, m0 = k0 + PW;
-                const int c0 = 16 * jc > m0 + PW ? 16 * jc : m0 + PW, cend = 16 * jc + 16 < n ? 16 * jc + 16 : n;
-                if (c0 < cend) {
-                    if (lane < cend - c0) CgLuPanelCplx::column(C, ldc, k0, PW, pivc + k0, c0 + lane);
-                    asm volatile("" ::: "memory");
-                    CgLuPanelCplx::tiles(C, n, ldc, k0, PW, m0, c0, cend, lane);
-                }
-                cg_flag_store(app_c + jc, qc + 1, lane);
-                jc += nh;
-                while (qc + 1 < npc && jc >= nbc) { ++qc; jc = first_block(qc, hc); }
-                did = true;
-                CG_STAMP_END(19)
-            } else if (rr) {
-                CG_STAMP_START(19)
-                const int k0 = qr * PW, m0 = k0 + PW;
-                const int c0 = 16 * jr > m0 + PW ? 16 * jr : m0 + PW, cend = 16 * jr + 16 < N ? 16 * jr + 16 : N;
+        while (idle < (1 << 22)) {
+            const int pr = cg_flag_load(pub_r), pc = cg_flag_load(pub_c);
+            int q = 0, ap = 0;
+            if (lane < 12) {
+                q = __hip_atomic_load(claim_r + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);       // claim_c follows claim_r
+                ap = __hip_atomic_load(app_r + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);        // app_c follows app_r
+            }
+            const bool pending = mine && q < limit;
+            if (!__ballot(pending)) break;                               // every task of both matrices has been claimed
+            const bool ready = pending && (isr ? pr : pc) > q && ap >= q;
+            const unsigned long long mu = __ballot(ready && j == ((q + 2) >> 1)), me = __ballot(ready);
+            if (!me) { ++idle; __builtin_amdgcn_s_sleep(1); continue; }
+            const int pick = (int)__builtin_ctzll(mu ? mu : me);          // urgent (the block a chain waits for) first; real before complex
+            const int tq = __builtin_amdgcn_readlane(q, pick);
+            int got = 0;
+            if (lane == 0) got = atomicCAS(claim_r + pick, tq, tq + 1) == tq ? 1 : 0;
+            if (!__builtin_amdgcn_readfirstlane(got)) continue;          // another helper took it
+            CG_STAMP_START(19)
+            const int k0 = tq * PW, m0 = k0 + PW;
+            if (pick < 8) {
+                const int c0 = 16 * pick > m0 + PW ? 16 * pick : m0 + PW, cend = 16 * pick + 16 < N ? 16 * pick + 16 : N;
                 if (c0 < cend) {
                     if (lane < cend - c0) CgLuPanelReal::column(A, lda, k0, PW, pivr + k0, c0 + lane);
                     asm volatile("" ::: "memory");
                     CgLuPanelReal::tiles(A, N, lda, k0, PW, m0, c0, cend, lane);
                 }
-                cg_flag_store(app_r + jr, qr + 1, lane);
-                jr += nh;
-                while (qr + 1 < npr && jr >= nbr) { ++qr; jr = first_block(qr, hidx); }
-                did = true;
-                CG_STAMP_END(19)
+            } else {
+                const int jb = pick - 8;
+                const int c0 = 16 * jb > m0 + PW ? 16 * jb : m0 + PW, cend = 16 * jb + 16 < n ? 16 * jb + 16 : n;
+                if (c0 < cend) {
+                    if (lane < cend - c0) CgLuPanelCplx::column(C, ldc, k0, PW, pivc + k0, c0 + lane);
+                    asm volatile("" ::: "memory");
+                    CgLuPanelCplx::tiles(C, n, ldc, k0, PW, m0, c0, cend, lane);
+                }
             }
-            if (!did) { ++idle; __builtin_amdgcn_s_sleep(1); }
+            cg_flag_store(app_r + pick, tq + 1, lane);
+            CG_STAMP_END(19)
         }
     }
     b.sync();
