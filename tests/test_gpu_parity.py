@@ -333,6 +333,36 @@ def test_large_n_against_c_oracle(n, Emax, B):
     assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
 
 
+@pytest.mark.parametrize("n,Emax,B,ws", [(29, 25, 5, 1.5), (57, 49, 3, 1.2), (20, 25, 4, 2.0), (33, 25, 3, 1.5)])
+def test_large_n_with_row_exchanges_against_c_oracle(n, Emax, B, ws):
+    """The concurrent, flag-decoupled blocked LUs (cg_blocked_lu_dual) with a flow far from the identity (random weights of
+    standard deviation ws: the Jacobian is not diagonally dominant, the threshold test fails and rows are exchanged inside the
+    panels, with the rest of the exchange deferred to the helpers' column tasks); ragged last panels and blocks (N = 40, 66)."""
+    import ctypes as C
+    import coulombgas_amd as cg
+    from coulombgas_amd.build import build_oracle
+    lib = C.CDLL(build_oracle())
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    dim, L = 2, box_length(n, 2)
+    rng = np.random.default_rng(100 + n)
+    sp = orbitals(2, Emax)
+    theta = flow_theta(rng, 2, 16, 16, dim, ws, 0.2)
+    x = walkers(rng, B, n, dim, L)
+    sidx = state_indices(rng, B, n, sp.shape[0])
+    flow = cg.FermiNet(2, 16, 16, L)
+    eng = flow.engine(n, dim, sp)
+    eng.set_params(theta)
+    out = np.zeros((B, 3))
+    lib.cgo_logpsi(n, dim, 2, 16, 16, C.c_double(L), p(theta), p(sp), sp.shape[0], p(sidx), p(x), B, p(out))
+    lphi, hld = eng.logphi_logjacdet(x, sidx)
+    assert np.abs(lphi[:, 0] - out[:, 0]).max() < 1e-9 * np.abs(out[:, 0]).max()
+    assert np.abs(np.angle(np.exp(1j * (lphi[:, 1] - out[:, 1])))).max() < 1e-9
+    assert np.abs(hld - out[:, 2]).max() < 1e-9 * max(1.0, np.abs(out[:, 2]).max())
+    J = np.asarray(eng.flow_jacobian(x)).reshape(B, n * dim, n * dim)
+    d = np.abs(np.diagonal(J, axis1=1, axis2=2)); off = np.abs(J).sum(-1) - d
+    assert (off > d).any()                              # the case does exercise pivoting: J is not diagonally dominant
+
+
 def test_beyond_the_lds_limit_runs_on_the_general_path():
     """Maximum size: at n = 72 (N = 144) J alone is 162 KB, more than the 160 KB of LDS; the same depth-2 model then runs
     on the general path (HBM workspace) with identical results (C oracle) instead of failing."""
