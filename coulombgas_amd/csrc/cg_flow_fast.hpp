@@ -1008,6 +1008,15 @@ struct CgFast {
             CG_STAMP(12)
             double* res = (double*)perm;
             const int wave = b.tid >> 6, cw = b.nthr > 64 ? 1 : 0;
+            if (b.nthr == 64 && (n == 13 || n == 16) && n * D == 2 * n) {
+                // single-wave workgroup: both factorisations interleaved in one instruction stream
+                double lr, l2, a2;
+                if (n == 13) cg_wave_lu2_both<26, 13>(lds + o.J, 2 * n, 2 * n, lds + o.lus, lds + o.Dm, n, n, lds + o.lus + 32, lr, l2, a2);
+                else cg_wave_lu2_both<32, 16>(lds + o.J, 2 * n, 2 * n, lds + o.lus, lds + o.Dm, n, n, lds + o.lus + 32, lr, l2, a2);
+                half_logdetJ = 0.5 * lr; la = l2; ar = a2;
+                CG_STAMP(13)
+                CG_STAMP(14)
+            } else {
             if (wave == 0) {
                 const int NN = n * D;
                 const double v = NN == 26 ? cg_wave_lu2_logabsdet<26>(lds + o.J, NN, NN, lds + o.lus)
@@ -1026,6 +1035,7 @@ struct CgFast {
             half_logdetJ = 0.5 * res[0]; la = res[1]; ar = res[2];
             b.sync();
             CG_STAMP(14)
+            }
         } else {
             // larger sizes: workgroup-wide blocked LUs (4-column panels on wave 0, MFMA trailing updates on every wave).
             // The Slater matrix may share J's LDS (o.Dm == o.J), so it is formed after the real factorisation.

@@ -433,6 +433,132 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
     logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
     arg = cg_atan2_ool(pm.im, pm.re);
 }
+// Both determinants of one walker in ONE instruction stream (single-wave workgroups, n <= 16): the real step k and -- on every
+// other k -- a complex step are issued together.  Each factorisation alone is a chain of dependent f64 operations (~12 cycles
+// per instruction at two waves per SIMD); interleaved, one chain's latencies are filled by the other's instructions.  The two
+// rarely-taken pivot searches share one branch, so that the common path of a step is a single basic block the scheduler can
+// interleave.  Arithmetic per matrix identical to cg_wave_lu2_logabsdet / cg_wave_lu2_logdet_complex (same results).
+// NR = 2 NC.  scr_r, scr_c: 32 doubles of LDS each.
+template <int NR, int NC>
+__device__ __forceinline__ void cg_wave_lu2_both(const double* A, int N, int lda, double* scr_r, const double* Cm, int n, int ldc, double* scr_c,
+                                                 double& logabs_r, double& logabs_c, double& arg_c) {
+    constexpr int MH = NR / 2, MHP = (MH + 1) & ~1, MQ = (NC + 3) / 4;
+    const int lane = threadIdx.x & 63;
+    const int rr = lane >> 1, rc_ = lane & 1;            // real: row, column parity
+    const int cr = lane >> 2, cc = lane & 3;             // complex: row, column mod 4
+    double a[MH];
+#pragma unroll
+    for (int m = 0; m < MH; ++m) { const int j = 2 * m + rc_; a[m] = (rr < N && j < N) ? A[rr * lda + j] : 0.0; }
+    double ar[MQ], ai[MQ];
+#pragma unroll
+    for (int m = 0; m < MQ; ++m) {
+        const int j = 4 * m + cc; const bool ok = cr < n && j < n;
+        ar[m] = ok ? Cm[2 * (cr * ldc + j)] : 0.0; ai[m] = ok ? Cm[2 * (cr * ldc + j) + 1] : 0.0;
+    }
+    bool rdone = rr >= N, cdone = cr >= n;
+    unsigned long long rmask = N >= 32 ? 0ull : ~0ull << (2 * N), cmask = n >= 16 ? 0ull : ~0ull << (4 * n);
+    int mypos = cr, parity = 0;
+    double* rmine = scr_r + rc_ * MHP;
+    double* cmine = scr_c + 2 * cc;
+    CgScaledProd prod; prod.init();
+    CgCplx pm = {1.0, 0.0}; int pe = 0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const bool rs = k < N;                           // (wave-uniform) real step k
+        const int kc = k >> 1;
+        const bool cs = (k & 1) == 0 && kc < NC && kc < n;   // complex step kc rides on the even real steps
+        if (!rs && !cs) continue;
+        // ---- candidates
+        const int ck = k & 1, mk = k >> 1;
+        const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);
+        int p = (int)__builtin_ctzll(~rmask);
+        double piv = cg_readlane_f64(ak, p);
+        const int qk = kc & 3, qm = kc >> 2;
+        double akr = 0.0, aki = 0.0;
+        if (cs) {
+            if (qk == 0) { akr = cg_dpp_f64<0x00>(ar[qm]); aki = cg_dpp_f64<0x00>(ai[qm]); }
+            else if (qk == 1) { akr = cg_dpp_f64<0x55>(ar[qm]); aki = cg_dpp_f64<0x55>(ai[qm]); }
+            else if (qk == 2) { akr = cg_dpp_f64<0xAA>(ar[qm]); aki = cg_dpp_f64<0xAA>(ai[qm]); }
+            else { akr = cg_dpp_f64<0xFF>(ar[qm]); aki = cg_dpp_f64<0xFF>(ai[qm]); }
+        }
+        const double m2 = akr * akr + aki * aki;
+        int pc = (int)__builtin_ctzll(~cmask);
+        const unsigned long long tr = rs ? __ballot(!rdone && fabs(ak) * 0.25 > fabs(piv)) : 0ull;
+        const unsigned long long tc = cs ? __ballot(!cdone && m2 * 0.0625 > cg_readlane_f64(m2, pc)) : 0ull;
+        if (tr | tc) {                                   // a candidate more than 4x larger than the first unfinished row: full search
+            if (tr) {
+                const unsigned key = rdone ? 0u : (unsigned)(__double_as_longlong(fabs(ak)) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !rdone);
+                p = mask ? (int)__builtin_ctzll(mask) : p;
+                piv = cg_readlane_f64(ak, p);
+            }
+            if (tc) {
+                const unsigned key = cdone ? 0u : (unsigned)(__double_as_longlong(m2) >> 32) + 1u;
+                const unsigned mx = cg_wave_max_u32(key);
+                const unsigned long long mask = __ballot(key == mx && !cdone);
+                pc = mask ? (int)__builtin_ctzll(mask) : pc;
+            }
+        }
+        // ---- multipliers
+        const bool risp = rr == (p >> 1);
+        double l = 0.0;
+        if (rs) {
+            prod.mul(piv);
+            const double rinv = cg_fast_rcp1(piv);
+            l = (rdone || risp) ? 0.0 : ak * rinv;
+        }
+        const bool cisp = cr == (pc >> 2);
+        CgCplx lc = {0.0, 0.0};
+        if (cs) {
+            const int posp = __builtin_amdgcn_readlane(mypos, pc);
+            parity ^= (posp != kc) ? 1 : 0;
+            if (mypos == kc) mypos = posp;
+            if (cisp) mypos = kc;
+            const CgCplx cpiv = {cg_readlane_f64(akr, pc), cg_readlane_f64(aki, pc)};
+            pm = cmul(pm, cpiv);
+            if ((kc & 3) == 3) {
+                int ex; const double mxv = fmax(fabs(pm.re), fabs(pm.im)); (void)frexp(mxv, &ex);
+                pm.re = ldexp(pm.re, -ex); pm.im = ldexp(pm.im, -ex); pe += ex;
+            }
+            const double rd = cg_fast_rcp1(cpiv.re * cpiv.re + cpiv.im * cpiv.im);
+            const CgCplx rinv = {cpiv.re * rd, -cpiv.im * rd};
+            lc = cmul({akr, aki}, rinv);
+            if (cdone || cisp) { lc.re = 0.0; lc.im = 0.0; }
+        }
+        // ---- pivot rows through LDS (written by their owners, read back by every lane; in-order per wave), updates
+        const int m0 = ck ? mk + 1 : mk;
+        const int q0 = qk == 3 ? qm + 1 : qm;
+        if (rs && risp) {
+#pragma unroll
+            for (int m = m0; m < MH; ++m) rmine[m] = a[m];
+        }
+        if (cs && cisp) {
+#pragma unroll
+            for (int m = q0; m < MQ; ++m) { cmine[8 * m] = ar[m]; cmine[8 * m + 1] = ai[m]; }
+        }
+        asm volatile("" ::: "memory");
+        if (rs) {
+#pragma unroll
+            for (int m = m0; m < MH; ++m) a[m] = fma(-l, rmine[m], a[m]);
+        }
+        if (cs) {
+#pragma unroll
+            for (int m = q0; m < MQ; ++m) {
+                const double pr = cmine[8 * m], pi = cmine[8 * m + 1];
+                ar[m] = fma(-lc.re, pr, fma(lc.im, pi, ar[m]));
+                ai[m] = fma(-lc.re, pi, fma(-lc.im, pr, ai[m]));
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (rs) { rdone = rdone || risp; rmask |= 3ull << (p & ~1); }
+        if (cs) { cdone = cdone || cisp; cmask |= 15ull << (pc & ~3); }
+    }
+    if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
+    logabs_r = prod.logabs(true);
+    logabs_c = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    arg_c = cg_atan2_ool(pm.im, pm.re);
+}
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
