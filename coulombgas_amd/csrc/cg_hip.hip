@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) k_van(CgVanModel m, const double* __restr
 }
 
 // per-sample gradients of log p (cg_van_gradient): one wave per sample; stash: (n-1) * token-stash doubles per wave in HBM
-__global__ void __launch_bounds__(256) k_van_grad(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
+__global__ void __launch_bounds__(512) k_van_grad(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
                                                   const int* __restrict__ sidx, double* __restrict__ S, double* __restrict__ stash_all, int plds) {
     extern __shared__ double van_lds[];
     const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
@@ -582,9 +582,17 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
         c->van_scores_cap = need;
     }
     const size_t pbytes = sizeof(double) * (size_t)((m.total + 1) & ~1), wbytes = sizeof(double) * (size_t)cg_van_grad_wave_doubles(m);
-    int waves = 4, plds = 1;
-    while (waves > 1 && pbytes + waves * wbytes > 160 * 1024) --waves;
-    if (pbytes + waves * wbytes > 160 * 1024) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
+    // workgroup shape: as many waves per CU as the 160 KB of LDS allow with the weights staged once per workgroup (the kernel is
+    // latency-bound: one wave per SIMD left it at 8.0 ms for B = 8192, n = 13)
+    int waves = 0, plds = 1;
+    { int best = 0;
+      for (int w = 1; w <= 8; ++w) {
+          const size_t need = pbytes + w * wbytes;
+          if (need > 160 * 1024) break;
+          const int per_cu = w * (int)((160 * 1024) / need);
+          if (per_cu > best) { best = per_cu; waves = w; }
+      } }
+    if (waves == 0) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
     const size_t lds = (plds ? pbytes : 0) + waves * wbytes;
     if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van_scores_compute: one sample needs %zu bytes of LDS", wbytes);
     const int grid = std::min((B + waves - 1) / waves, c->cu_count * 4);

@@ -183,8 +183,19 @@ __device__ __forceinline__ double cg_van_sequence(const CgVanModel& m, const dou
 // pass over the tokens n-2 .. 0 and the layers top down.  Key / value adjoints of a position are complete when the reverse
 // pass reaches it (every later query has contributed), so one sweep suffices.  The gradient row (cg_van_num_params doubles,
 // flat parameter order) is accumulated in HBM with a fixed entry <-> lane mapping: deterministic.
+// G[i][j] += a[i] d[j]; the read-modify-writes of the gradient row (HBM / L2) go four at a time so that their latencies overlap
 __device__ __forceinline__ void cg_van_outer(double* __restrict__ G, const double* a, const double* d, int nin, int nout, int lane) {
-    for (int e = lane; e < nin * nout; e += 64) { const int i = e / nout, j = e - i * nout; G[e] = fma(a[i], d[j], G[e]); }
+    const int tot = nin * nout;
+    for (int e0 = lane; e0 < tot; e0 += 256) {
+        double g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = e0 + 64 * u; g[u] = e < tot ? G[e] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 64 * u;
+            if (e < tot) { const int i = e / nout, j = e - i * nout; G[e] = fma(a[i], d[j], g[u]); }
+        }
+    }
 }
 __device__ __forceinline__ void cg_van_vadd(double* __restrict__ G, const double* d, int nout, int lane) {
     for (int j = lane; j < nout; j += 64) G[j] += d[j];
@@ -312,7 +323,13 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
             dy[r] = (lg[r] > -INFINITY) ? (j == nxt ? 1.0 : 0.0) - exp(lg[r] - mx) / z : 0.0;
             if (j < M && dy[r] != 0.0) {
                 G[m.o_ob + j] += dy[r];
-                for (int i = 0; i < ms; ++i) G[m.o_ow + i * M + j] = fma(th[i], dy[r], G[m.o_ow + i * M + j]);
+                for (int i0 = 0; i0 < ms; i0 += 8) {                               // eight read-modify-writes in flight
+                    double g[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) g[u] = i0 + u < ms ? G[m.o_ow + (i0 + u) * M + j] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (i0 + u < ms) G[m.o_ow + (i0 + u) * M + j] = fma(th[i0 + u], dy[r], g[u]);
+                }
             }
         }
         for (int i = 0; i < ms; ++i) {                                             // dh = (Wout dy) (1 - th^2)
