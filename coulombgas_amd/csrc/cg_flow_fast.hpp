@@ -1037,8 +1037,9 @@ struct CgFast {
             CG_STAMP(14)
             }
         } else {
-            // larger sizes: workgroup-wide blocked LUs (4-column panels on wave 0, MFMA trailing updates on every wave).
-            // The Slater matrix may share J's LDS (o.Dm == o.J), so it is formed after the real factorisation.
+            // larger sizes: workgroup-wide blocked LUs (8-column register panels, MFMA trailing updates).  With both matrices in
+            // LDS (o.dual) they are factored concurrently; otherwise the Slater matrix shares J's LDS (o.Dm == o.J) and is
+            // formed after the real factorisation.
             double* res = (double*)perm;
             if (o.dual && b.nthr >= 192 && b.nthr <= 1024 && n * D <= 128 && n <= 64) {
                 // both matrices have LDS of their own: the Slater matrix is formed first and the two LUs run concurrently
