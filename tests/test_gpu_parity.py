@@ -333,7 +333,7 @@ def test_large_n_against_c_oracle(n, Emax, B):
     assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
 
 
-@pytest.mark.parametrize("n,Emax,B,ws", [(29, 25, 5, 1.5), (57, 49, 3, 1.2), (20, 25, 4, 2.0), (33, 25, 3, 1.5)])
+@pytest.mark.parametrize("n,Emax,B,ws", [(29, 25, 5, 1.5), (57, 49, 3, 1.2), (20, 25, 4, 2.0), (33, 25, 3, 1.5), (45, 49, 2, 1.2), (25, 25, 3, 1.5)])
 def test_large_n_with_row_exchanges_against_c_oracle(n, Emax, B, ws):
     """The concurrent, flag-decoupled blocked LUs (cg_blocked_lu_dual) with a flow far from the identity (random weights of
     standard deviation ws: the Jacobian is not diagonally dominant, the threshold test fails and rows are exchanged inside the
