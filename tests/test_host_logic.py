@@ -429,3 +429,33 @@ def test_freefermion_pretraining_and_exact_free_energy():
     s = np.array(list(itertools.combinations(range(10), n)))[:32]
     val, aux = loss(pv, s)
     assert np.isfinite(val) and set(aux) == {"E_mean", "E_std", "F_mean", "F_std", "S_mean", "S_std"}
+
+
+def test_transformer_flat_parameter_order_and_missing_engine():
+    """Host side of the device Transformer: flat_params (the order of cg_van_set_params, include/coulombgas.h) and unflat_params
+    are inverse to each other, also with leading axes (per-sample gradients); the permutation DeviceScores hands to
+    cg_van_scores_fisher maps ravel_pytree order (jax.flatten_util: sorted keys) to that flat order; and the density-matrix
+    closures refuse to run without a GPU engine unless the numpy restatement is asked for explicitly."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.autoregressive import flat_params, unflat_params
+    from coulombgas_amd.sr import ravel_pytree
+    van = cg.Transformer(10, 2, 16, 4, 32)
+    sp10 = orbitals(2)[:10]
+    params = van.init(3, sp10[:4])
+    flat = flat_params(van, params, 2)
+    count = sum(int(np.prod(v.shape)) for m in params.values() for v in m.values())
+    assert flat.shape == (count,)
+    back = unflat_params(van, flat, 2)
+    for m in params:
+        for l in params[m]:
+            assert np.array_equal(back[m][l], params[m][l])
+    batched = unflat_params(van, np.stack([flat, 2 * flat]), 2)              # leading batch axis
+    assert batched[van.name]["x1hat"].shape == (2, 10) and np.array_equal(batched[van.name + "/output_mlp"]["w"][1], 2 * params[van.name + "/output_mlp"]["w"])
+    perm = ravel_pytree(unflat_params(van, np.arange(count), 2))[0].astype(int)
+    assert sorted(perm.tolist()) == list(range(count))
+    assert np.array_equal(ravel_pytree(params)[0], flat[perm])
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp10, 4, 10)
+    with pytest.raises(RuntimeError):
+        sampler(params, 0, 8)
+    with pytest.raises(RuntimeError):
+        log_prob(params, np.array([[0, 1, 2, 3]]))
