@@ -240,6 +240,8 @@ CG_DEVI double cg_log_ge1(double w) {
 #endif
     return fma((double)ex, 0.693147180559945309417232121458, cg_log_12(m));
 }
+// log(w) for a positive normal w (any exponent), -inf for w = 0
+CG_DEVI double cg_log_pos(double w) { return w > 0.0 ? cg_log_ge1(w) : -INFINITY; }
 CG_DEVI double softplus_only(double u) {
     const double e = cg_exp_nonpos(-fabs(u));
     const double w = 1.0 + e;
@@ -254,8 +256,10 @@ struct CgScaledProd {
     CG_DEVI void mul(double v) {
         int ex; m = frexp(m * v, &ex); e += ex;
     }
+    // ool = true (kernels): the mantissa is in [1/2, 1) after frexp, its logarithm comes from the [1, 2) table routine
+    // (~15 instructions) instead of the out-of-line libm call (~100 with the call) -- once or twice per log Psi evaluation
     CG_DEVI double logabs(bool ool = false) const {
-        return (ool ? cg_log_ool(fabs(m)) : log(fabs(m))) + (double)e * 0.693147180559945309417232121458;
+        return (ool ? cg_log_pos(fabs(m)) : log(fabs(m))) + (double)e * 0.693147180559945309417232121458;
     }
 };
 

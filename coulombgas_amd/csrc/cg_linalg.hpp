@@ -430,7 +430,7 @@ __device__ __forceinline__ void cg_wave_lu2_logdet_complex(const double* A, int 
         }
     }
     if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
-    logabs = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    logabs = 0.5 * cg_log_pos(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
     arg = cg_atan2_ool(pm.im, pm.re);
 }
 // Both determinants of one walker in ONE instruction stream (single-wave workgroups, n <= 16): the real step k and -- on every
@@ -556,7 +556,7 @@ __device__ __forceinline__ void cg_wave_lu2_both(const double* A, int N, int lda
     }
     if (parity) { pm.re = -pm.re; pm.im = -pm.im; }
     logabs_r = prod.logabs(true);
-    logabs_c = 0.5 * cg_log_ool(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
+    logabs_c = 0.5 * cg_log_pos(pm.re * pm.re + pm.im * pm.im) + (double)pe * 0.693147180559945309417232121458;
     arg_c = cg_atan2_ool(pm.im, pm.re);
 }
 #endif
