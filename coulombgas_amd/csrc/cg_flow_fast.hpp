@@ -1066,7 +1066,7 @@ struct CgFast {
             cg_lu_logdet_complex(b, lds + o.Dm, n, n, perm, la, ar, true);
         }
 #endif
-        re_phi = la - (double)n * (0.5 * D) * cg_log_ool(L);
+        re_phi = la - (double)n * (0.5 * D) * cg_log_pos(L);      // (table logarithm: this was the last libm call of an evaluation)
         im_phi = ar;
     }
 };
