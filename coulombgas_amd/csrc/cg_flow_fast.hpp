@@ -121,6 +121,8 @@ struct CgFast {
         const double* th;
         double tw[P + 1];  // two-particle layer column h = lane & 15: bias, then P weights  (pair-primal pass)
         bool inline_libm;  // true: keep sincos inline (derivative kernels: see CG_OUTLINE in cg_common.hpp)
+        bool wt_resident;  // true: the caller staged the two-particle weights into o.wt once (stage_wt) and nothing overwrites that
+                           // slot between evaluations (Metropolis chain at small n); false: jacobian_mfma stages them itself
     };
     struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
     struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
@@ -130,7 +132,7 @@ struct CgFast {
     static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; }
+    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; w.wt_resident = false; }
     static __device__ __forceinline__ void load_pair_cols(const double* __restrict__ th_in, WFrag& w) {
         const double* th = th_in;
         asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
@@ -563,6 +565,17 @@ struct CgFast {
             }
         }
     }
+    // two-particle layer weights [h][bias, P weights] and Wf (HS x D) from the parameter vector into the LDS slot o.wt
+    static __device__ __forceinline__ void stage_wt(const CgBlk& b, const double* __restrict__ th, double* lds, const CgFastLds& o) {
+        double* wt = lds + o.wt;
+        double* wfl = wt + HT * (P + 1);
+        for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
+            const int h = e / (P + 1), f = e - h * (P + 1);
+            wt[e] = f == 0 ? th[o_t0b + h] : th[o_t0w + (f - 1) * HT + h];
+        }
+        for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
+        b.sync();
+    }
     // The whole Jacobian assembly on the MFMA / DPP path (double, spsize = tpsize = 16).  Order chosen so that
     // V can reuse Bm's LDS slot:  U,Bm | G  ->  Up  ->  J = Bm G  ->  V  ->  J += pair part  ->  diagonal blocks.
     static __device__ __forceinline__ void jacobian_mfma(const CgBlk& b, const double* __restrict__ th, const WFrag& w, int n,
@@ -573,12 +586,7 @@ struct CgFast {
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
         double* wt = lds + o.wt;
         double* wfl = wt + HT * (P + 1);
-        for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
-            const int h = e / (P + 1), f = e - h * (P + 1);
-            wt[e] = f == 0 ? th[o_t0b + h] : th[o_t0w + (f - 1) * HT + h];
-        }
-        for (int e = b.tid; e < HS * D; e += b.nthr) wfl[e] = th[o_fw + e];
-        b.sync();
+        if (!w.wt_resident) stage_wt(b, th, lds, o);
         CG_STAMP(4)
         jac_factors_mfma<0>(b, w, n, lds, o, wfl);
         CG_STAMP(5)
