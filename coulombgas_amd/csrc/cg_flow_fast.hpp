@@ -988,7 +988,7 @@ struct CgFast {
                                       const int* __restrict__ sidx, int n, double* Dm, bool ool = false) {
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = e / n, j = e - i * n;
-            const double* k = spk + (size_t)sidx[j] * D;
+            const double* k = sidx ? spk + (size_t)sidx[j] * D : spk + j * D;      // sidx == nullptr: spk already holds the n occupied k
             double ph = 0.0;
 #pragma unroll
             for (int a = 0; a < D; ++a) ph += k[a] * z[i * D + a];

@@ -404,7 +404,7 @@ int cg_get_launch_info(cg_ctx* c, int64_t* info) {
     if (!c || !info) return CG_ERR_ARG;
     const int N = c->n * c->dim;
     info[0] = threads_of(c);
-    info[1] = (int64_t)sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    info[1] = (int64_t)sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 3 * ((N + 1) & ~1) + 2);
     info[2] = c->cu_count; info[3] = c->P; info[4] = c->fast ? 1 : 0; info[5] = info[6] = info[7] = 0;
     return CG_OK;
 }

@@ -99,7 +99,7 @@ int cg_mcmc(cg_ctx* c, double* x, const int32_t* sidx, int B, int mc_steps, doub
         return CG_OK;
     }
     const int nt = threads_of(c);
-    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 2 * ((N + 1) & ~1) + 2);
+    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + c->lay.total + 3 * ((N + 1) & ~1) + 2);   // + x, proposal, flag, k-vectors
     const CgDev m = make_dev(c);
     bool launched = false;
     if ((rc = cg_sampler_a_mcmc(c, nt, lds, m, (double*)ax.dev, (const int*)as.dev, B, mc_steps, mc_stddev, seed, walker_offset,
