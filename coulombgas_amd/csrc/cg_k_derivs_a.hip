@@ -25,41 +25,105 @@ __global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int 
 // Quantum Fisher matrix of stochastic reconfiguration (src/sr.py:74-76):  F[p][q] = (1/B) sum_b Re( conj(S[b][p]) S[b][q] )
 // = (1/B) sum_b ( Sr[b][p] Sr[b][q] + Si[b][p] Si[b][q] ),  S = per-sample scores (B x P, complex interleaved).
 // One wave per 16 x 16 tile of the upper triangle (mirrored on store); the batch axis is the K of v_mfma_f64_16x16x4.
-__global__ void __launch_bounds__(256) k_fisher(const double* __restrict__ S, int B, int P, double* __restrict__ F) {
+#define CG_MFMA_4X4(acc, av, bv)                                                                                          \
+    _Pragma("unroll") for (int a_ = 0; a_ < 4; ++a_)                                                                      \
+        _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_)(acc)[a_][c_] = __builtin_amdgcn_mfma_f64_16x16x4f64((av)[a_], (bv)[c_], (acc)[a_][c_], 0, 0, 0)
+// Same blocking as k_fisher_real (csrc/cg_solve.inc): one wave owns a 64 x 64 block of F as 4 x 4 MFMA tiles, MFMA row i of tile
+// a is parameter 4 i + a (a lane's eight operands -- four complex entries -- are 64 contiguous bytes of a score row), the operands
+// of step t + 1 are in flight while step t multiplies, upper block-triangle only, the batch sliced over blockIdx.z (partial
+// matrices summed in fixed order by k_rows_sum_d) because P = 1074 alone gives only 45 workgroups.
+__global__ void __launch_bounds__(256, 2) k_fisher(const double* __restrict__ S, int B, int P, int chunk, double scale, double* __restrict__ F) {
     typedef double d4_t __attribute__((ext_vector_type(4)));
+    if (blockIdx.x < blockIdx.y) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles = (P + 15) >> 4;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= tiles * tiles) return;
-    const int ti = tile / tiles, tj = tile - ti * tiles;
-    if (tj < ti) return;
+    const int p0 = 128 * blockIdx.y + 64 * (wave >> 1), q0 = 128 * blockIdx.x + 64 * (wave & 1);
+    if (p0 >= P || q0 >= P || q0 + 64 <= p0) return;
     const int col = lane & 15, kq = lane >> 4;
-    const int p = 16 * ti + col, q = 16 * tj + col;
-    const bool pok = p < P, qok = q < P;
-    d4_t acc = {0, 0, 0, 0};
-    for (int b1 = 0; b1 < B; b1 += 16) {
+    const int b0 = blockIdx.z * chunk, b1 = min(B, b0 + chunk);
+    F += (size_t)blockIdx.z * P * P;
+    d4_t acc[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {                 // four independent load groups in flight per trip
-            const int b = b1 + 4 * u + kq;
-            const bool bok = b < B;
-            const double* sa = S + ((size_t)b * P + p) * 2;
-            const double* sb = S + ((size_t)b * P + q) * 2;
-            const double a_re = (bok && pok) ? sa[0] : 0.0, a_im = (bok && pok) ? sa[1] : 0.0;
-            const double b_re = (bok && qok) ? sb[0] : 0.0, b_im = (bok && qok) ? sb[1] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re, b_re, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im, b_im, acc, 0, 0, 0);
-        }
-    }
-    const double rb = 1.0 / (double)B;
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pr = 16 * ti + kq + 4 * r;
-        if (pr < P && qok) {
-            const double v = acc[r] * rb;
-            F[(size_t)pr * P + q] = v;
-            if (ti != tj) F[(size_t)q * P + pr] = v;
+        for (int c = 0; c < 4; ++c) acc[a][c] = d4_t{0, 0, 0, 0};
+    const int pl = p0 + 4 * col, ql = q0 + 4 * col;
+    int bb = b0;
+    if (p0 + 64 <= P && q0 + 64 <= P && b1 - b0 >= 8) {                   // interior block (wave-uniform)
+        const double* pa = S + ((size_t)(b0 + kq) * P + pl) * 2;
+        const double* pb = S + ((size_t)(b0 + kq) * P + ql) * 2;
+        const size_t step = (size_t)8 * P;
+        double ar[4], ai[4], br[4], bi[4], anr[4], ani[4], bnr[4], bni[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { ar[a] = pa[2 * a]; ai[a] = pa[2 * a + 1]; br[a] = pb[2 * a]; bi[a] = pb[2 * a + 1]; }
+        const int steps = (b1 - b0) >> 2;
+        for (int t = 1; t < steps; ++t) {
+            pa += step; pb += step;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { anr[a] = pa[2 * a]; ani[a] = pa[2 * a + 1]; bnr[a] = pb[2 * a]; bni[a] = pb[2 * a + 1]; }
+            CG_MFMA_4X4(acc, ar, br);
+            CG_MFMA_4X4(acc, ai, bi);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { ar[a] = anr[a]; ai[a] = ani[a]; br[a] = bnr[a]; bi[a] = bni[a]; }
         }
+        CG_MFMA_4X4(acc, ar, br);
+        CG_MFMA_4X4(acc, ai, bi);
+        bb = b0 + 4 * steps;
     }
+    for (; bb < b1; bb += 4) {                                            // ragged blocks and the last rows of the batch
+        const int b = bb + kq;
+        double ar[4], ai[4], br[4], bi[4];
+        const double* rowp = S + (size_t)min(b, B - 1) * P * 2;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const bool pa_ok = b < b1 && pl + a < P, pb_ok = b < b1 && ql + a < P;
+            ar[a] = pa_ok ? rowp[2 * (pl + a)] : 0.0; ai[a] = pa_ok ? rowp[2 * (pl + a) + 1] : 0.0;
+            br[a] = pb_ok ? rowp[2 * (ql + a)] : 0.0; bi[a] = pb_ok ? rowp[2 * (ql + a) + 1] : 0.0;
+        }
+        CG_MFMA_4X4(acc, ar, br);
+        CG_MFMA_4X4(acc, ai, bi);
+    }
+    const bool mirror = q0 != p0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = p0 + 4 * (kq + 4 * r) + a;
+            if (pr >= P) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int q = ql + c;
+                if (q < P) {
+                    const double v = acc[a][c][r] * scale;
+                    F[(size_t)pr * P + q] = v;
+                    if (mirror) F[(size_t)q * P + pr] = v;
+                }
+            }
+        }
+}
+// out[p] = scale * sum_r partial[r][p], rows summed in fixed order
+__global__ void k_rows_sum_d(const double* __restrict__ partial, int rows, int P, double scale, double* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += partial[(size_t)r * P + p];
+    out[p] = a * scale;
+}
+// Re(S^H S) / B of the resident complex scores into F (device pointer); partial matrices from the arena when the batch is sliced
+static int fisher_complex_launch(cg_ctx* c, const double* S, int B, int P, double* F) {
+    const int nbt = (P + 127) / 128, blocks = nbt * (nbt + 1) / 2;
+    int nsl = 1;
+    while (nsl < 16 && blocks * nsl < c->cu_count && B / (2 * nsl) >= 64) nsl *= 2;
+    const int chunk = (((B + nsl - 1) / nsl) + 3) & ~3;
+    if (nsl == 1) {
+        hipLaunchKernelGGL(k_fisher, dim3(nbt, nbt, 1), dim3(256), 0, c->stream, S, B, P, chunk, 1.0 / (double)B, F);
+    } else {
+        double* part = (double*)arena_take(c, sizeof(double) * (size_t)nsl * P * P);
+        if (!part) CG_FAIL(c, CG_ERR_HIP, "quantum Fisher matrix: workspace allocation failed");
+        hipLaunchKernelGGL(k_fisher, dim3(nbt, nbt, nsl), dim3(256), 0, c->stream, S, B, P, chunk, 1.0, part);
+        hipLaunchKernelGGL(k_rows_sum_d, dim3((P * P + 255) / 256), dim3(256), 0, c->stream, (const double*)part, nsl, P * P, 1.0 / (double)B, F);
+    }
+    CG_HIP(c, hipGetLastError());
+    return CG_OK;
 }
 // mean over the batch of the complex scores (src/sr.py:70): out[2 p + c] = (1/B) sum_b S[b][p][c]; fixed summation order
 // Column sums of the resident score matrix over one slice of the batch (blockIdx.y): out[slice][c] = sum_{b in slice} S[b][c].
@@ -199,8 +263,7 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     if (g_theta)
         hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
     if (fisher) {
-        const int tiles = (P + 15) / 16;
-        hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)asc.dev, B, P, (double*)afi.dev);
+        if ((rc = fisher_complex_launch(c, (const double*)asc.dev, B, P, (double*)afi.dev))) return rc;
         if (smean && (rc = score_reduce(c, (const double*)asc.dev, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
     }
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
@@ -249,8 +312,7 @@ int cg_scores_fisher(cg_ctx* c, double* fisher, double* score_mean) {
     Arg asm_{score_mean, nullptr, sizeof(double) * (size_t)P * 2, false, true};
     Arg* all[] = {&afi, &asm_};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    const int tiles = (P + 15) / 16;
-    hipLaunchKernelGGL(k_fisher, dim3((tiles * tiles + 3) / 4), dim3(256), 0, c->stream, (const double*)c->d_scores, B, P, (double*)afi.dev);
+    if ((rc = fisher_complex_launch(c, (const double*)c->d_scores, B, P, (double*)afi.dev))) return rc;
     if ((rc = score_reduce(c, (const double*)c->d_scores, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
