@@ -1,8 +1,8 @@
 """coulombgas_amd -- MI355X-native VMC hot path of fermiflow/CoulombGas.
 
 Exports the names main.py takes from the reference's `src` package for this path
-(src/__init__.py:1-13) plus the SR optimizer (src/sr.py); the checkpoint format and a host-side forward pass of the
-autoregressive Transformer sampler (src/autoregressive.py, src/sampler.py); with its gradients, and the free-fermion
+(src/__init__.py:1-13) plus the SR optimizer (src/sr.py), the checkpoint format, the autoregressive Transformer density
+matrix (src/autoregressive.py, src/sampler.py: sampler, log-probability and gradients on the GPU) and the free-fermion
 pre-training (src/freefermion/pretraining.py)."""
 from .flow import FermiNet
 from .potential import kpoints, Madelung, potential_energy

@@ -1,31 +1,15 @@
-"""Host-side (numpy) forward pass of the autoregressive Transformer of src/autoregressive.py and the sampler /
-log-probability of src/sampler.py.  It produces the integer `state_indices` the accelerated hot path consumes and the
-entropy term log p of the loss; it is n tiny batched matmuls per sampling call and stays on the host.
-
-Gradients of log p w.r.t. the parameters (jax.grad(log_prob), src/sampler.py:65: the classical score of the SR optimizer
-and the VJP jax.jacrev(classical_lossfn) needs) come from a hand-written reverse pass of the same forward code
-(`log_prob.grad` / `log_prob.vjp` / `make_classical_score`).  Parameters keep Haiku's names and shapes, so shipped
-`params_van` (checkpoints, pretrained models) load unchanged."""
-import contextlib
+"""The autoregressive Transformer density matrix of src/autoregressive.py / src/sampler.py on the GPU: this module is the
+host-side mirror of the reference's interface (Transformer, make_autoregressive_sampler, make_classical_score) on top of the
+device kernels of csrc/cg_van.hpp (cg_van_sample / cg_van_log_prob / cg_van_scores_*: sampler, log-probability, per-sample
+scores, weighted VJP, classical Fisher matrix).  Parameters keep Haiku's names and shapes, so shipped `params_van`
+(checkpoints, pretrained models) load unchanged.  There is no host fallback: the closures raise without a GPU engine (a numpy
+restatement of the same functions lives under tests/ as a checker)."""
 import numpy as np
 
 
-def _blas_limit():
-    """The model is tiny (16-wide): thousands of small batched matmuls.  On many-core hosts an unrestricted BLAS thread pool
-    turns each of them into a synchronisation storm (measured: minutes instead of milliseconds on a 256-thread box)."""
-    try:
-        from threadpoolctl import threadpool_limits
-        return threadpool_limits(limits=4, user_api="blas")
-    except Exception:
-        return contextlib.nullcontext()
-
-
-def _linear(p, x):
-    return x @ p["w"] + p["b"]
-
-
 class Transformer:
-    """src/autoregressive.py:50-96.  apply(params, None, x): x (..., n, dim) -> logits (..., n, output_size)."""
+    """src/autoregressive.py:50-96: architecture, parameter tree (Haiku names / shapes) and initialiser.  The forward and
+    reverse passes run on the device (csrc/cg_van.hpp)."""
 
     def __init__(self, output_size, num_layers, model_size, num_heads, hidden_size, name="transformer"):
         if model_size % num_heads != 0:
@@ -72,100 +56,6 @@ class Transformer:
                     fan = shp[1] if mod.endswith("embedding_mlp") else shp[0]      # "fan_out" for the embedding (:75)
                     out[mod][leaf] = trunc(shp, np.sqrt(scale / fan) / 0.87962566103423978)
         return out
-
-    # -- forward ---------------------------------------------------------------------------------------------
-    def _attention(self, params, i, x):
-        nm = "%s/layer%d_attn/" % (self.name, i)
-        T = x.shape[-2]
-        H, K = self.num_heads, self.key_size
-        # heads to the front: (..., H, T, K); batched matmuls (numpy's einsum is ~5x slower on these shapes)
-        split = lambda y: np.swapaxes(y.reshape(y.shape[:-1] + (H, K)), -2, -3)
-        q, k, v = (split(_linear(params[nm + part], x)) for part in ("query", "key", "value"))
-        logits = (q @ np.swapaxes(k, -1, -2)) / np.sqrt(K)
-        mask = np.tril(np.ones((T, T), dtype=bool))                                # CausalSelfAttention, :26-27
-        logits = np.where(mask, logits, -1e30)
-        logits = logits - logits.max(axis=-1, keepdims=True)
-        w = np.exp(logits); w /= w.sum(axis=-1, keepdims=True)
-        attn = np.swapaxes(w @ v, -2, -3)                                          # (..., T, H, K)
-        return _linear(params[nm + "linear"], attn.reshape(attn.shape[:-2] + (H * K,)))
-
-    def forward_cache(self, params, x):
-        """apply() keeping what the reverse pass needs.  x (B, T, dim)."""
-        nm, H, K = self.name, self.num_heads, self.key_size
-        x0 = np.asarray(x, dtype=np.float64)
-        T = x0.shape[-2]
-        h = np.tanh(_linear(params[nm + "/embedding_mlp"], x0))
-        cache = {"x0": x0, "h0": h, "layers": []}
-        mask = np.tril(np.ones((T, T), dtype=bool))
-        for i in range(self.num_layers):
-            an = "%s/layer%d_attn/" % (nm, i)
-            split = lambda y: np.swapaxes(y.reshape(y.shape[:-1] + (H, K)), -2, -3)       # (B, H, T, K)
-            q, k, v = (split(_linear(params[an + part], h)) for part in ("query", "key", "value"))
-            lg = np.where(mask, (q @ np.swapaxes(k, -1, -2)) / np.sqrt(K), -1e30)
-            lg = lg - lg.max(axis=-1, keepdims=True)
-            A = np.exp(lg); A /= A.sum(axis=-1, keepdims=True)
-            o = np.swapaxes(A @ v, -2, -3).reshape(h.shape[:-1] + (H * K,))
-            h1 = h + _linear(params[an + "linear"], o)
-            m = np.tanh(_linear(params["%s/layer%d_mlp/linear" % (nm, i)], h1))
-            h2 = h1 + _linear(params["%s/layer%d_mlp/linear_1" % (nm, i)], m)
-            cache["layers"].append({"hin": h, "q": q, "k": k, "v": v, "A": A, "o": o, "h1": h1, "m": m})
-            h = h2
-        th = np.tanh(h)
-        y = _linear(params[nm + "/output_mlp"], th)
-        cache["th"] = th
-        x1hat = np.broadcast_to(params[nm]["x1hat"], y.shape[:-2] + (1, self.output_size))
-        return np.concatenate([x1hat, y[..., :-1, :]], axis=-2), cache
-
-    def backward(self, params, cache, dlogits, per_sample):
-        """Reverse pass: dlogits (B, T, output_size) -> parameter gradients, with a leading batch axis on every leaf when
-        per_sample, otherwise summed over the batch."""
-        nm, H, K = self.name, self.num_heads, self.key_size
-        B, T = dlogits.shape[0], dlogits.shape[1]
-        wsum = ((lambda a, d: np.swapaxes(a, 1, 2) @ d) if per_sample else
-                (lambda a, d: a.reshape(-1, a.shape[-1]).T @ d.reshape(-1, d.shape[-1])))
-        bsum = (lambda d: d.sum(axis=1)) if per_sample else (lambda d: d.sum(axis=(0, 1)))
-        g = {nm: {"x1hat": dlogits[:, 0, :] if per_sample else dlogits[:, 0, :].sum(axis=0)}}
-        dy = np.concatenate([dlogits[:, 1:, :], np.zeros((B, 1, self.output_size))], axis=1)
-        po = params[nm + "/output_mlp"]
-        g[nm + "/output_mlp"] = {"w": wsum(cache["th"], dy), "b": bsum(dy)}
-        dh = (dy @ po["w"].T) * (1.0 - cache["th"] ** 2)
-        for i in reversed(range(self.num_layers)):
-            c = cache["layers"][i]
-            an = "%s/layer%d_attn/" % (nm, i)
-            p1, p2 = params["%s/layer%d_mlp/linear" % (nm, i)], params["%s/layer%d_mlp/linear_1" % (nm, i)]
-            g["%s/layer%d_mlp/linear_1" % (nm, i)] = {"w": wsum(c["m"], dh), "b": bsum(dh)}
-            dpre = (dh @ p2["w"].T) * (1.0 - c["m"] ** 2)
-            g["%s/layer%d_mlp/linear" % (nm, i)] = {"w": wsum(c["h1"], dpre), "b": bsum(dpre)}
-            dh1 = dh + dpre @ p1["w"].T
-            pl = params[an + "linear"]
-            g[an + "linear"] = {"w": wsum(c["o"], dh1), "b": bsum(dh1)}
-            do = np.swapaxes((dh1 @ pl["w"].T).reshape(B, T, H, K), 1, 2)                  # (B, H, T, K)
-            dA = do @ np.swapaxes(c["v"], -1, -2)
-            dv = np.swapaxes(c["A"], -1, -2) @ do
-            dS = c["A"] * (dA - (c["A"] * dA).sum(axis=-1, keepdims=True)) / np.sqrt(K)
-            merge = lambda y: np.swapaxes(y, 1, 2).reshape(B, T, H * K)
-            dq = merge(dS @ c["k"])
-            dk = merge(np.swapaxes(dS, -1, -2) @ c["q"])
-            dv = merge(dv)
-            dhin = dh1
-            for part, d in (("query", dq), ("key", dk), ("value", dv)):
-                g[an + part] = {"w": wsum(c["hin"], d), "b": bsum(d)}
-                dhin = dhin + d @ params[an + part]["w"].T
-            dh = dhin
-        dpre0 = dh * (1.0 - cache["h0"] ** 2)
-        g[nm + "/embedding_mlp"] = {"w": wsum(cache["x0"], dpre0), "b": bsum(dpre0)}
-        return g
-
-    def apply(self, params, rng, x):
-        nm = self.name
-        x = np.tanh(_linear(params[nm + "/embedding_mlp"], np.asarray(x, dtype=np.float64)))
-        for i in range(self.num_layers):
-            x = x + self._attention(params, i, x)
-            h = np.tanh(_linear(params["%s/layer%d_mlp/linear" % (nm, i)], x))
-            x = x + _linear(params["%s/layer%d_mlp/linear_1" % (nm, i)], h)
-        x = _linear(params[nm + "/output_mlp"], np.tanh(x))
-        x1hat = np.broadcast_to(params[nm]["x1hat"], x.shape[:-2] + (1, self.output_size))
-        return np.concatenate([x1hat, x[..., :-1, :]], axis=-2)                    # :93
 
 
 def flat_params(network, params, dim):
@@ -229,108 +119,61 @@ class DeviceScores:
         return a if dtype is None else a.astype(dtype)
 
 
-def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None, host=False):
+def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=False, engine=None):
     """src/sampler.py:4-50 with a leading batch axis built in (the reference vmaps).  sampler(params, key, batch) ->
     (batch, n) int32 sorted state indices; log_prob(params, state_indices (batch, n)) -> (batch,).
     engine (or sampler.attach(engine) later; coulombgas_amd.train does it): a GPU Engine of the same (n, dim) -- the sampler
-    and the log-probability then run on the device (cg_van_sample / cg_van_log_prob: one wave per sample, key / value cache
+    and the log-probability run on the device (cg_van_sample / cg_van_log_prob: one wave per sample, key / value cache
     in LDS) and hand DeviceArrays to the hot path, and the gradients (log_prob.grad -> DeviceScores, log_prob.vjp) come from
-    the device's reverse pass (cg_van_scores_*).  Calling the closures with no engine attached raises: the numpy
-    restatement below is the checker of the device kernels (tests) and runs only when asked for with host=True."""
+    the device's reverse pass (cg_van_scores_*).  Calling the closures with no engine attached raises."""
     sp_indices = np.asarray(sp_indices, dtype=np.float64)
     base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
     dev = {"engine": engine}
 
     def _dev_engine(params):
         eng = dev["engine"]
-        if eng is None and not host:
+        if eng is None:
             raise RuntimeError("autoregressive density matrix: no GPU engine attached (pass engine= / call .attach(engine); "
-                               "coulombgas_amd.train attaches its own).  host=True selects the numpy restatement used by the tests.")
-        if eng is not None:
-            eng.van_set_params((num_states, network.num_layers, network.model_size, network.num_heads, network.hidden_size),
-                               sp_indices, flat_params(network, params, sp_indices.shape[1]))
+                               "coulombgas_amd.train attaches its own)")
+        eng.van_set_params((num_states, network.num_layers, network.model_size, network.num_heads, network.hidden_size),
+                           sp_indices, flat_params(network, params, sp_indices.shape[1]))
         return eng
 
     def _mask(state_idx):
+        """src/sampler.py:72-91 (host logic: which orbitals each electron may still take)"""
         state_idx = np.asarray(state_idx)
         idx_lb = np.concatenate([np.full(state_idx.shape[:-1] + (1,), -1), state_idx[..., :-1]], axis=-1)
         return base & (np.arange(num_states) > idx_lb[..., None])
 
-    def _logits(params, state_idx):
-        logits = network.apply(params, None, sp_indices[state_idx])
-        return np.where(_mask(state_idx), logits, -1e50)
-
     def sampler(params, key, batch, unif=None):
         eng = _dev_engine(params)
-        if eng is not None:
-            from .mcmc import _seed_of
-            return eng.van_sample_d(batch, 0 if unif is not None else _seed_of(key), 0, unif)[0]
-        with _blas_limit():
-            return _sampler(params, key, batch, unif)
-
-    def _sampler(params, key, batch, unif=None):
-        rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
-        state_indices = np.zeros((batch, n), dtype=np.int32)
-        for i in range(n):
-            # the conditional of electron i needs positions <= i only (causal attention): run the prefix, not all n
-            logits = network.apply(params, None, sp_indices[state_indices[:, :i + 1]])[:, i, :]
-            logits = np.where(_mask(state_indices)[:, i, :], logits, -1e50)
-            u = rng.uniform(size=logits.shape) if unif is None else np.asarray(unif)[:, i, :]
-            g = -np.log(-np.log(u))                                                # Gumbel-max = jax.random.categorical
-            state_indices[:, i] = np.argmax(logits + g, axis=-1)
-        return state_indices
+        from .mcmc import _seed_of
+        return eng.van_sample_d(batch, 0 if unif is not None else _seed_of(key), 0, unif)[0]
 
     def log_prob(params, state_idx):
         eng = _dev_engine(params)
-        if eng is not None:
-            if hasattr(state_idx, "ptr"):
-                return eng.van_log_prob_d(state_idx)
-            return eng.van_log_prob(state_idx)
-        state_idx = np.asarray(state_idx)
-        with _blas_limit():
-            logits = _logits(params, state_idx)
-        m = logits.max(axis=-1, keepdims=True)
-        logp = logits - m - np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
-        return np.take_along_axis(logp, state_idx[..., None], axis=-1)[..., 0].sum(axis=-1)
-
-    def _dlogits(params, state_idx):
-        state_idx = np.asarray(state_idx)                  # (a DeviceArray downloads here: the gradients are host numpy)
-        logits, cache = network.forward_cache(params, sp_indices[state_idx])
-        logits = np.where(_mask(state_idx), logits, -1e50)
-        m = logits.max(axis=-1, keepdims=True)
-        p = np.exp(logits - m); p /= p.sum(axis=-1, keepdims=True)
-        d = -p
-        np.put_along_axis(d, state_idx[..., None], np.take_along_axis(d, state_idx[..., None], axis=-1) + 1.0, axis=-1)
-        return d, cache                                       # d log p / d logits = onehot - softmax (0 on masked entries)
+        if hasattr(state_idx, "ptr"):
+            return eng.van_log_prob_d(state_idx)
+        return eng.van_log_prob(state_idx)
 
     def _dev_scores(params, state_idx):
         eng = _dev_engine(params)
-        if eng is None:
-            return None
         s_d = state_idx if hasattr(state_idx, "ptr") else eng.asdevice(np.asarray(state_idx, dtype=np.int32), "van_sidx_in", np.int32)
         eng.van_scores_compute_d(s_d)
         return eng
 
     def grad(params, state_idx):
-        """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients, every leaf with a leading batch axis (host), or
-        a DeviceScores handle with an engine attached."""
+        """jax.vmap(jax.grad(log_prob), (None, 0), 0): per-sample gradients as a DeviceScores handle (np.asarray / .tree()
+        download them)."""
         eng = _dev_scores(params, state_idx)
-        if eng is not None:
-            return DeviceScores(eng, network, sp_indices.shape[1], int(np.shape(state_idx)[0]))
-        with _blas_limit():
-            d, cache = _dlogits(params, state_idx)
-            return network.backward(params, cache, d, per_sample=True)
+        return DeviceScores(eng, network, sp_indices.shape[1], int(np.shape(state_idx)[0]))
 
     def vjp(params, state_idx, w):
         """sum_b w[b] * d log_prob_b / d params  (what jax.jacrev of a weighted sum of log-probabilities returns)."""
         eng = _dev_scores(params, state_idx)
-        if eng is not None:
-            w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w")
-            g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1],)))
-            return unflat_params(network, eng.to_host(g), sp_indices.shape[1])
-        with _blas_limit():
-            d, cache = _dlogits(params, state_idx)
-            return network.backward(params, cache, d * np.asarray(w, dtype=np.float64)[:, None, None], per_sample=False)
+        w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w")
+        g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1],)))
+        return unflat_params(network, eng.to_host(g), sp_indices.shape[1])
 
     log_prob.grad, log_prob.vjp = grad, vjp
 

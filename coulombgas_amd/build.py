@@ -45,9 +45,12 @@ def _compile_units(objdir, flags, force=False):
             cmd = [hipcc] + HIP_FLAGS + list(flags) + ["-c", "-o", obj, src]
             print("+", " ".join(cmd), flush=True)
             jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in jobs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+    failed = None
+    for cmd, p in jobs:                                   # wait for every job (no orphan still writing .o files), then report
+        if p.wait() != 0 and failed is None:
+            failed = (p.returncode, cmd)
+    if failed is not None:
+        raise subprocess.CalledProcessError(*failed)
     return objs
 
 

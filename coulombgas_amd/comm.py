@@ -47,7 +47,12 @@ class TorchDistComm:
 
     def pmean_d(self, a, count=None, index=0):
         """array handles of the CPU test engine are numpy arrays: all-reduce in place"""
+        if not isinstance(a, np.ndarray):
+            raise TypeError("TorchDistComm.pmean_d works on the numpy handles of the CPU test engine; device arrays of a GPU "
+                            "engine are reduced by RcclComm (got %s)" % type(a).__name__)
         flat = a.reshape(-1)
+        if index < 0 or (count is not None and index + count > flat.size):
+            raise IndexError("pmean_d: [%d, %d) outside an array of %d elements" % (index, index + (count or 0), flat.size))
         n = flat.size - index if count is None else count
         flat[index:index + n] = self.pmean(flat[index:index + n])
         return a
@@ -96,7 +101,11 @@ class RcclComm:
         """in-place RCCL all-reduce (mean) of a DeviceArray, or of `count` doubles from element `index` of its buffer, on the
         engine's stream: no host staging (main.py:280, src/VMC.py:46-53, src/sr.py:73-82)"""
         from ._lib import lib, check
+        base = a.base                                        # a DeviceArray is its own base (index 0); a DeviceView a window
+        total = base.size * (2 if base.complex_pairs else 1) - a.index        # doubles from a's first element to the buffer's end
         n = (a.size * (2 if a.complex_pairs else 1) - index) if count is None else count
+        if index < 0 or n < 0 or index + n > total:
+            raise IndexError("pmean_d: [%d, %d) outside a device buffer of %d doubles" % (index, index + n, total))
         check(lib().cg_allreduce_mean(self._h, a.ptr_at(index), int(n)), self.engine._ctx)
         a.version += 1
         return a

@@ -6,9 +6,11 @@ thermalisation rounds (:241-246) and the data.txt row format (:367-372).
 
 The variational density matrix is passed as `sampler`, `log_prob` (+ `log_prob_vjp`, the vector-Jacobian product
 jax.jacrev(classical_lossfn) needs, and `classical_score_fn` if params_van is to be trained).  With
-coulombgas_amd.make_autoregressive_sampler (the reference's Transformer, host numpy) all four come from one object.
+coulombgas_amd.make_autoregressive_sampler (the reference's Transformer, run on the GPU: csrc/cg_van.hpp) all four come from
+one object.
 `GroundStateSampler` is the trivial stand-in (zero temperature: every walker in the n lowest orbitals, log_prob = 0)."""
 import os
+import warnings
 import numpy as np
 from . import sr as _sr
 from .comm import get_comm, allgather
@@ -181,19 +183,32 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
     opt_state = optimizer.init((params_van, params_flow))
     ss = np.random.SeedSequence(seed).spawn(cm.world)[cm.rank]                        # :237, one key per device
     eng = flow.engine(n, dim, sp_indices)
-    first_epoch = 1
+    first_epoch = epoch_finished + 1                                                   # main.py:316 in both branches
     load_name = ckpt_filename(epoch_finished, ckpt_path) if ckpt_path is not None else None
+    if epoch_finished > 0 and (load_name is None or not os.path.isfile(load_name)):
+        # the reference (main.py:217-223) starts from scratch at epoch_finished + 1 in this case; say so, it is rarely meant
+        warnings.warn("train: epoch_finished=%d but no checkpoint %s: starting from fresh walkers and parameters at epoch %d"
+                      % (epoch_finished, load_name, first_epoch))
     if load_name is not None and epoch_finished > 0 and os.path.isfile(load_name):     # :217-223 resume
+        # (ckpt_path must be the same on every rank: the checkpoint all-gather below is a collective)
         ck = load_data(load_name)
         xs = np.asarray(ck["x"], dtype=np.float64)
-        x = xs[cm.rank] if xs.ndim == 4 else xs                                        # leading device axis of the reference
+        if xs.ndim == 4:                                                               # leading device axis of the reference
+            if xs.shape[0] != cm.world:
+                raise ValueError("checkpoint %s holds walkers of %d devices, this run has %d ranks" % (load_name, xs.shape[0], cm.world))
+            x = xs[cm.rank]
+        else:
+            x = xs
         params_van, params_flow = ck["params_van"], ck["params_flow"]
         st = adam_state_from_ckpt(ck.get("opt_state"))
         if st is not None and isinstance(opt_state, dict):
+            if params_van is None and isinstance(st.get("mu"), (tuple, list)) and st["mu"] and st["mu"][0] is not None:
+                st = dict(st, mu=(None,) + tuple(st["mu"][1:]), nu=(None,) + tuple(st["nu"][1:]))   # moments of a density matrix this run does not train
             opt_state = st
+        elif ck.get("opt_state") is not None and isinstance(opt_state, dict):
+            warnings.warn("train: the optimizer state of %s could not be adopted; Adam moments restart at zero" % load_name)
         ks = np.asarray(ck["keys"])
         key = np.random.SeedSequence([int(v) for v in np.atleast_2d(ks)[cm.rank % np.atleast_2d(ks).shape[0]].ravel()])
-        first_epoch = epoch_finished + 1
         thermalise = False
     else:
         rng = np.random.default_rng(ss)

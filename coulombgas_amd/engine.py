@@ -4,9 +4,12 @@ Host-side mirror of what the reference's closures capture (main.py:152-171): the
 architecture, the orbital table `sp_indices_twist`, the box L and the Ewald constants.
 """
 import ctypes as C
+import itertools
 import numpy as np
 from . import _lib
 from ._lib import lib, check
+
+_TOKENS = itertools.count(1)      # identity of device arrays / parameter sets in cache keys: never reused (id() is, after a free)
 
 
 def _f64(a):
@@ -60,6 +63,7 @@ class DeviceArray:
         self.complex_pairs = bool(complex_pairs)
         self.buf = DeviceBuffer(eng, self.shape + ((2,) if complex_pairs else ()), self.dtype)
         self.version = 0          # bumped by every call that writes the buffer (cache keys)
+        self.token = next(_TOKENS)  # which array this is, for cache keys (monotonic: a recycled address is not a match)
         self.base, self.index = self, 0
 
     ndim = property(lambda self: len(self.shape))
@@ -110,6 +114,7 @@ class DeviceView:
     size = property(lambda self: int(np.prod(self.shape, dtype=np.int64)))
     ptr = property(lambda self: self.base.ptr_at(self.index))
     version = property(lambda self: self.base.version, lambda self, v: setattr(self.base, "version", v))
+    token = property(lambda self: (self.base.token, self.index, self.shape))
 
     def ptr_at(self, i):
         return self.base.ptr_at(self.index + int(i))
@@ -143,6 +148,7 @@ class Engine:
         self.device = int(device)
         self.P = lib().cg_num_params(ctx)
         self._theta = None
+        self._theta_version = 0       # bumped whenever new flow parameters reach the device (cache keys)
         self._ewald = None
         self._mode = _lib.CG_PTR_HOST
 
@@ -168,6 +174,7 @@ class Engine:
         if self._theta is None or not np.array_equal(theta, self._theta):
             check(lib().cg_set_flow_params(self._ctx, _p(theta)), self._ctx)
             self._theta = theta.copy()
+            self._theta_version += 1
 
     def set_ewald(self, kappa, G, rs):
         G = np.ascontiguousarray(G, dtype=np.int64)
@@ -307,10 +314,11 @@ class Engine:
         if B == 0 or B * self.P * 16 > self.SCORE_CACHE_MAX_BYTES:
             return False
         key = getattr(self, "_score_key", None)
-        if key is not None and key[2] is self._theta and key[0].shape == xb.shape and np.array_equal(key[0], xb) and np.array_equal(key[1], s):
+        if key is not None and key[2] == self._theta_version and key[0].shape == xb.shape and np.array_equal(key[0], xb) and np.array_equal(key[1], s):
             return True
+        self._score_key = self._score_key_d = None      # the resident scores are about to be overwritten: neither key describes them
         check(lib().cg_scores_compute(self._ctx, _p(xb), _p(s), B), self._ctx)
-        self._score_key = (xb.copy(), s.copy(), self._theta)
+        self._score_key = (xb.copy(), s.copy(), self._theta_version)
         return True
 
     def param_vjp(self, x, state_idx, w_re, w_im, use_scores=True):
@@ -350,7 +358,7 @@ class Engine:
         if self._mode == _lib.CG_PTR_HOST and self._scores_ready(xb, s):
             check(lib().cg_scores_fisher(self._ctx, _p(F), _p(sm)), self._ctx)
         else:
-            self._score_key = None      # cg_quantum_fisher overwrites the resident scores: the cached key no longer describes them
+            self._score_key = self._score_key_d = None      # cg_quantum_fisher overwrites the resident scores: no cached key describes them
             check(lib().cg_quantum_fisher(self._ctx, _p(xb), _p(s), B, _p(F), _p(sm)), self._ctx)
         return F, sm[:, 0] + 1j * sm[:, 1]
 
@@ -508,11 +516,11 @@ class Engine:
     def scores_compute_d(self, x_d, sidx_d):
         """per-sample scores S = d log Psi / d theta resident on the device (src/logpsi.py:183-203); recomputed only when the
         walkers, the state indices or theta changed"""
-        key = (id(x_d), x_d.version, id(sidx_d), sidx_d.version, id(self._theta))
+        key = (x_d.token, x_d.version, sidx_d.token, sidx_d.version, self._theta_version)
         if getattr(self, "_score_key_d", None) != key:
+            self._score_key = self._score_key_d = None          # (also if the call below fails half-way)
             self._dev_call(lib().cg_scores_compute, x_d.ptr, sidx_d.ptr, int(x_d.shape[0]))
             self._score_key_d = key
-            self._score_key = None          # the host-mode cache describes other walkers now
 
     def scores_vjp_d(self, w_re_d, w_im_d, out, out_index=0):
         self._dev_call(lib().cg_scores_vjp, w_re_d.ptr, w_im_d.ptr, out.ptr_at(out_index))
@@ -590,12 +598,12 @@ class Engine:
         u = self.asdevice(unif, "van_unif") if unif is not None else None
         self._dev_call(lib().cg_van_sample, int(B), int(seed) & (2 ** 64 - 1), int(offset), u.ptr if u is not None else None, sidx.ptr, logp.ptr)
         sidx.version += 1; logp.version += 1
-        logp.tag = (id(sidx), sidx.version, self._van_version)        # these log-probabilities belong to these samples + parameters
+        logp.tag = (sidx.token, sidx.version, self._van_version)      # these log-probabilities belong to these samples + parameters
         return sidx, logp
 
     def van_log_prob_d(self, sidx_d):
         cached = self.__dict__.get("_scratch", {}).get("van_logp")
-        if cached is not None and getattr(cached, "tag", None) == (id(sidx_d), sidx_d.version, self._van_version):
+        if cached is not None and getattr(cached, "tag", None) == (sidx_d.token, sidx_d.version, self._van_version):
             return cached                                                # computed by the sampling pass itself
         logp = self.scratch("van_logp2", (sidx_d.shape[0],))
         self._dev_call(lib().cg_van_log_prob, sidx_d.ptr, int(sidx_d.shape[0]), logp.ptr)
@@ -605,8 +613,9 @@ class Engine:
     def van_scores_compute_d(self, sidx_d):
         """per-sample classical scores d log p_b / d params (flat order) for these samples; resident in the context until the
         samples or the parameters change (cg_van_scores_compute)"""
-        key = (id(sidx_d), sidx_d.version, self._van_version)
+        key = (sidx_d.token, sidx_d.version, self._van_version)
         if getattr(self, "_van_scores_key", None) != key:
+            self._van_scores_key = None
             self._dev_call(lib().cg_van_scores_compute, sidx_d.ptr, int(sidx_d.shape[0]))
             self._van_scores_key = key
             self._van_scores_B = int(sidx_d.shape[0])

@@ -55,10 +55,11 @@ def make_loss(log_prob, Es, beta):
 
 
 def pretrain(van, params_van, n, dim, Theta, sp_indices_twist, key, lr=1e-3, sr=True, damping=1e-3, max_norm=1e-3,
-             batch=8192, epoch=5000, log=None, engine=None, host=False):
+             batch=8192, epoch=5000, log=None, engine=None, density_matrix=None):
     """src/freefermion/pretraining.py:34-108.  sp_indices_twist: the reversed twisted orbital table (main.py:79-90).
-    engine: a GPU Engine for (n, dim): the sampler, the log-probabilities, the reverse pass (per-sample scores, weighted VJP) and
-    the classical Fisher matrix + damped solve then run on the device.  host=True (tests): the numpy restatement instead.
+    engine: a GPU Engine for (n, dim) -- created here when None: the sampler, the log-probabilities, the reverse pass (per-sample
+    scores, weighted VJP) and the classical Fisher matrix + damped solve run on the device.
+    density_matrix: a (sampler, log_prob) pair to use instead (the CPU tests of this loop pass their numpy checker).
     Returns the trained params_van and the data.txt rows (epoch, F, F_std, E, E_std, S, S_std)."""
     if dim == 3:
         L = (4 / 3 * np.pi * n) ** (1 / 3); beta = 1 / ((4.5 * np.pi) ** (2 / 3) * Theta)
@@ -66,7 +67,13 @@ def pretrain(van, params_van, n, dim, Theta, sp_indices_twist, key, lr=1e-3, sr=
         L = np.sqrt(np.pi * n); beta = 1 / (4 * Theta)
     sp = np.asarray(sp_indices_twist, dtype=np.float64)
     Es = (2 * np.pi / L) ** 2 * (sp ** 2).sum(axis=-1)
-    sampler, log_prob = make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=engine, host=host)
+    if density_matrix is not None:
+        sampler, log_prob = density_matrix
+    else:
+        if engine is None:                                  # the density matrix needs no flow: any architecture, unit box
+            from .engine import Engine
+            engine = Engine(n, dim, 2, 16, 16, 1.0, sp)
+        sampler, log_prob = make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=engine)
     loss_fn = make_loss(log_prob, Es, beta)
     if sr:
         optimizer = _sr.fisher_sr(make_classical_score(log_prob), damping, max_norm, engine)

@@ -4,9 +4,10 @@
 The Fisher matrices are where the work is: the quantum one, Re(S^H S)/B over the per-sample scores
 S = d log Psi / d theta (src/logpsi.py:183-203), is formed on the GPU (cg_quantum_fisher: reverse passes for the
 scores, f64 MFMA SYRK, all on the device), and the centred, damped solve runs there too (cg_spd_solve: blocked Cholesky +
-triangular solves); the norm clip (src/sr.py:102-117) is O(P) host arithmetic.  The classical score function (the autoregressive Transformer, outside the
-accelerated path) is supplied by the caller and returns a (B, P_van) array (or a pytree of arrays with a leading
-batch axis, ravelled in sorted-key order like jax's ravel_pytree)."""
+triangular solves); the norm clip (src/sr.py:102-117) is O(P) host arithmetic.  The classical score function (the autoregressive
+Transformer; with coulombgas_amd.make_autoregressive_sampler its per-sample scores are formed and kept on the GPU as a
+DeviceScores handle, cg_van_scores_*) is supplied by the caller and returns that handle, a (B, P_van) array, or a pytree of
+arrays with a leading batch axis, ravelled in sorted-key order like jax's ravel_pytree."""
 from collections import namedtuple
 import numpy as np
 from .comm import get_comm

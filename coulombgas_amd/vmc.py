@@ -13,8 +13,8 @@ _I_E, _I_F = 4, 6          # positions of <E> and <F> in the moments vector (src
 
 def sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow, mc_steps, mc_stddev, L, comm=None):
     """src/VMC.py:8-25 for ONE device (one process per GPU replaces the pmap).
-    key: numpy SeedSequence (or int).  sampler(params_van, key_state, batch) -> (batch, n) int state indices
-    (the autoregressive sampler is outside the accelerated path and stays host code).
+    key: numpy SeedSequence (or int).  sampler(params_van, key_state, batch) -> (batch, n) int state indices: a numpy array
+    (GroundStateSampler) or a DeviceArray (the autoregressive Transformer samples on the GPU, cg_van_sample).
     x: numpy array, or a DeviceArray that is advanced in place (the reference donates x, src/VMC.py:11).
     Returns key, state_indices, x (wrapped into [0,L)), accept_rate (pmean'd)."""
     ss = key if isinstance(key, np.random.SeedSequence) else np.random.SeedSequence(int(key))

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from tests.common import orbitals, box_length, flow_theta, state_indices, walkers, GOLDEN as GOLDEN_DIR
+from tests.host_transformer import make_host_sampler
 
 pytestmark = pytest.mark.gpu
 
@@ -894,7 +895,7 @@ def test_transformer_density_matrix_on_device():
     chi2 = ((counts - B * p) ** 2 / (B * p)).sum()
     assert chi2 < len(states) + 6 * np.sqrt(2 * len(states)), chi2                               # chi-square, 209 d.o.f.
     # (iii) supplied uniforms: identical draws to the host restatement
-    hs, hlp = cg.make_autoregressive_sampler(van, sp10, n, M, host=True)
+    hs, hlp = make_host_sampler(van, sp10, n, M)
     u = rng.uniform(size=(512, n, M))
     assert np.array_equal(np.asarray(sampler(params, 0, 512, unif=u)), hs(params, 0, 512, unif=u))
     eng.close()
@@ -941,7 +942,7 @@ def test_transformer_density_matrix_on_device():
     eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp49)
     van = cg.Transformer(sp49.shape[0], 2, 16, 4, 32)
     sampler, log_prob = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], engine=eng)
-    _, hlp = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], host=True)
+    _, hlp = make_host_sampler(van, sp49, n, sp49.shape[0])
     s = np.asarray(sampler(pv, 5, 96))
     assert (np.diff(s, axis=1) > 0).all() and s.max() < sp49.shape[0]
     ref = hlp(pv, s)
@@ -994,7 +995,7 @@ def test_transformer_reverse_pass_on_device():
             for leaf in params[mod]:
                 params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
         sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M, engine=eng)
-        _, hlp = cg.make_autoregressive_sampler(van, sp, n, M, host=True)
+        _, hlp = make_host_sampler(van, sp, n, M)
         s_d = sampler(params, 3, B)
         s = np.asarray(s_d)
         sc = log_prob.grad(params, s_d)
@@ -1031,7 +1032,7 @@ def test_transformer_reverse_pass_on_device():
     eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp49)
     van = cg.Transformer(sp49.shape[0], 2, 16, 4, 32)
     sampler, log_prob = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], engine=eng)
-    _, hlp = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], host=True)
+    _, hlp = make_host_sampler(van, sp49, n, sp49.shape[0])
     s_d = sampler(pv, 5, 40)
     S = np.asarray(log_prob.grad(pv, s_d))
     Sh = _ravel_batched(hlp.grad(pv, np.asarray(s_d)))

@@ -8,6 +8,7 @@ import coulombgas_amd as cg
 from coulombgas_amd import flow as fl, vmc
 from oracle import cg_ref as R
 from tests import emul_engine
+from tests.host_transformer import make_host_sampler
 from tests.common import orbitals, box_length, flow_theta, state_indices, walkers, GOLDEN
 
 
@@ -199,7 +200,7 @@ def test_training_loop_runs_and_logs(monkeypatch):
     spm = sp[-M:]
     van = cg.Transformer(M, 1, 8, 2, 16)
     pv0 = van.init(2, spm[:n])
-    tsamp, tlogp = cg.make_autoregressive_sampler(van, spm, n, M, host=True)
+    tsamp, tlogp = make_host_sampler(van, spm, n, M)
     pv, pf, rows = cg.train(flow, p0, spm, n, dim, L, rs=2.0, beta=1 / (4 * 0.15), batch=8, epochs=2, sampler=tsamp, log_prob=tlogp,
                             params_van=pv0, sr=(1e-3, 1e-3), mc_therm=1, mc_steps=3, acc_steps=2, seed=1)
     vals = [float(v) for v in rows[-1].split()]
@@ -339,7 +340,7 @@ def test_autoregressive_sampler_kats():
     sp10 = orbitals(2)[-10:]
     van = cg.Transformer(10, 2, 16, 4, 32)
     params = van.init(0, sp10[:4])
-    mask_fn, sampler, log_prob = cg.make_autoregressive_sampler(van, sp10, 4, 10, mask_fn=True, host=True)
+    mask_fn, sampler, log_prob = make_host_sampler(van, sp10, 4, 10, mask_fn=True)
     si = np.array(list(itertools.combinations(range(10), 4)))
     assert np.exp(log_prob(params, si)).sum() == pytest.approx(1.0, abs=1e-12)
     m = mask_fn(np.array([1, 4, 5, 7])).astype(int)
@@ -355,7 +356,7 @@ def test_autoregressive_sampler_kats():
     spt = orbitals(2, 25)
     Es = (2 * np.pi / L) ** 2 * (spt ** 2).sum(-1)                                    # src/freefermion/pretraining.py:54
     van = cg.Transformer(spt.shape[0], 2, 16, 4, 32)
-    sampler, log_prob = cg.make_autoregressive_sampler(van, spt, n, spt.shape[0], host=True)
+    sampler, log_prob = make_host_sampler(van, spt, n, spt.shape[0])
     B = 4096
     s = sampler(pv, 1, B)
     lp = log_prob(pv, s)
@@ -377,7 +378,7 @@ def test_autoregressive_gradients_vs_torch_autograd():
     for mod in params:                                       # larger weights than the init so that every path matters
         for leaf in params[mod]:
             params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
-    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M, host=True)
+    sampler, log_prob = make_host_sampler(van, sp, n, M)
     s = sampler(params, 2, B)
     tp = {m: {l: R.T(v).requires_grad_(True) for l, v in params[m].items()} for m in params}
     lps = [R.autoregressive_log_prob(tp, torch.as_tensor(s[b].astype(np.int64)), R.T(sp), 2, 4) for b in range(B)]
@@ -419,12 +420,13 @@ def test_freefermion_pretraining_and_exact_free_energy():
         assert abs(Fx - pub) < 2e-4
     van = cg.Transformer(10, 1, 8, 2, 16)
     p0 = van.init(5, sp10[:n])
-    pv, rows = cg.pretrain(van, p0, n, 2, Theta, sp10, 11, sr=True, damping=1e-3, max_norm=1e-2, batch=1024, epoch=40, host=True)
+    pv, rows = cg.pretrain(van, p0, n, 2, Theta, sp10, 11, sr=True, damping=1e-3, max_norm=1e-2, batch=1024, epoch=40,
+                          density_matrix=make_host_sampler(van, sp10, n, 10))
     v = np.array([[float(t) for t in r.split()] for r in rows])
     assert v.shape == (40, 7) and np.isfinite(v).all()
     assert v[-5:, 1].mean() < v[0, 1] - 5 * v[0, 2]               # F went down by many standard errors
     assert v[-5:, 1].mean() > F - 5 * v[-5:, 2].mean()            # ... and respects the variational bound
-    _, log_prob = cg.make_autoregressive_sampler(van, sp10, n, 10, host=True)
+    _, log_prob = make_host_sampler(van, sp10, n, 10)
     loss = make_loss(log_prob, Es, beta)
     s = np.array(list(itertools.combinations(range(10), n)))[:32]
     val, aux = loss(pv, s)

@@ -20,7 +20,7 @@ if "--van" in sys.argv:                      # finite temperature: the shipped T
         if "|" in k:
             m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
     van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
-    s_fn, lp_fn = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=None if "--host-van" in sys.argv else flow.engine(n, 2, sp), host="--host-van" in sys.argv)
+    s_fn, lp_fn = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=flow.engine(n, 2, sp))
     samp = s_fn; samp.log_prob = lp_fn
 G = cg.kpoints(2, 15); Vconst = n * rs / L * cg.Madelung(2, 10, G)
 lp0 = cg.make_logpsi(flow, sp, L); logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L); logp = cg.make_logp(lp0)
