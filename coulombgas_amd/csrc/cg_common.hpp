@@ -16,10 +16,12 @@
 #define CG_HD __host__ __device__ __forceinline__
 #define CG_DEV __device__
 #define CG_DEVI __device__ __forceinline__
+#define CG_DEVN __device__ __attribute__((noinline))
 #else
 #define CG_HD inline
 #define CG_DEV
 #define CG_DEVI inline
+#define CG_DEVN inline
 #endif
 
 struct CgBlk {
@@ -276,6 +278,17 @@ CG_DEVI CgCplx cinv(CgCplx a) {
         double r = a.re / a.im, d = 1.0 / (a.re * r + a.im);
         return {r * d, -d};
     }
+}
+
+// e / d by multiply-shift for the index arithmetic of the work-item loops (d = n, n D: runtime values, and a 32-bit integer
+// division is ~30 VALU instructions): exact for e, d < 65536.  m = cg_div_magic(d), computed on the host.
+static CG_HD unsigned cg_div_magic(unsigned d) { return d <= 1 ? 0u : 0xFFFFFFFFu / d + 1u; }
+static CG_HD int cg_udiv(int e, unsigned m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return m ? (int)__umulhi((unsigned)e, m) : e;
+#else
+    return m ? (int)(((unsigned long long)(unsigned)e * m) >> 32) : e;
+#endif
 }
 
 // Deterministic (fixed-order) workgroup sum through LDS scratch of nthr doubles.

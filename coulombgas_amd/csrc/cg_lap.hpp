@@ -29,6 +29,7 @@ struct CgLap {
     static constexpr int P = F::P;
     static constexpr int NP = F::NPARAM;
     static constexpr int HM = HT > P ? HT : P;
+    static constexpr int PFS = 2 * D + 2;        // doubles per ordered pair in the pair table: c2[D], s2[D], del, 1/del
 
     // Three blocks, each wholly in LDS or wholly in the per-workgroup HBM workspace (decided on the host):
     //   P  persistent: x, g, xbar, J^-1 (and T^a, K^ab in mode 1: the probe pass needs them)
@@ -42,10 +43,11 @@ struct CgLap {
         int th_lds, th;     // 1: theta is copied to LDS at doubles offset th
         int P_lds, A_lds, B_lds;             // block placement
         unsigned P_off, A_off, B_off;        // block base (doubles) in its pool
+        unsigned mn, mN;    // multiply-shift constants of e / n and e / (n D) (cg_div_magic)
         // P
         int red, x, gz, xbar, Jinv, Ta, Kd, TaKd_in_P;
         // A
-        int da, Jc, Dc, Dinv, perm, C;
+        int da, pt, Jc, Dc, Dinv, perm, C;
         int Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, u2b, u1b, s1b, m1b, gbb, su2, m0b, rbar;
         int Lm0, gu1, Ls1, Lm1, Lgb, Am, Hk, SQ, Er, Su2, Ls2;
         // B
@@ -57,6 +59,7 @@ struct CgLap {
     static Lay layout(int n, int nthr, int mode, size_t lds_budget_doubles, bool theta_in_lds = true) {
         const size_t N = (size_t)n * D, NN = N * N, nn2 = 2 * (size_t)n * n;
         Lay l; memset(&l, 0, sizeof(l));
+        l.mn = cg_div_magic((unsigned)n); l.mN = cg_div_magic((unsigned)N);
         {   // jet arena: the aliased sampler layout (cg_fast_layout(alias = true)) with the weight scratch sized in doubles
             CgFastLds& j = l.oj; int t = 0;
             auto tk = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
@@ -91,7 +94,9 @@ struct CgLap {
         o.perm = take(2); o.wt = take(HT * (P + 1) + HS * D);
         o.U = take(N * HS); o.V = take((size_t)n * (HT * D + 2)); o.Bm = take((size_t)n * (HS * D + 2)); o.Up = take(N * P);
         o.G = take((size_t)n * (HS * D + 2));
-        if (!l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
+        // pair table: the features of every ordered pair (i, k), computed ONCE per walker in the set-up; every pair loop of the
+        // reverse sweep and of the forward Laplacian reads a row of it instead of recomputing ~90 instructions per pair
+        l.pt = take((size_t)n * n * PFS);
         const size_t A1 = t;
         // R3: J, Slater matrix (dead after the Slater part);  R2: primal temporaries;  then the set-up scratch
         o.J = take(NN); o.Dm = take(nn2); o.lus = take(2);
@@ -99,6 +104,8 @@ struct CgLap {
         o.m0 = take((size_t)n * P); o.s1 = take((size_t)n * HS); o.m1 = take((size_t)n * HT); o.gbar = take(HS); o.cb = take(HS); o.s2 = take((size_t)n * HS);
         o.total = (int)t; o.wave_lu = 0;
         l.Jc = take(NN); l.Dc = take(nn2); l.Dinv = take(nn2); l.perm = take(N + 42);
+        // T^a, diag K^ab live from the set-up to the Slater part only (modes 0, 2): behind the set-up scratch, under the adjoints
+        if (!l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
         size_t A_size = t;
         t = A2; l.C = take(NN); A_size = t > A_size ? t : A_size;
         t = A1;
@@ -155,11 +162,35 @@ struct CgLap {
         }
     };
 
-    struct TCol { double tc[D], ts[D], td[D], rdel; };
-    static CG_DEVI void tcols(const typename F::PairF& pf, double c1, double c2c, TCol& t) {
-        t.rdel = 1.0 / pf.del;
+    // One ordered pair (i, k) from the pair table: features of r_ik and the non-zeros of T_ik = d t0_ik / d r_ik
+    //   tc_b = d cos(2 pi r_b / L) / d r_b,  ts_b = d sin(2 pi r_b / L) / d r_b,  td_b = d |sin(pi r / L)| / d r_b
+    // Diagonal entries hold the exact diagonal feature [1.., 0.., 0] with 1/del = 0 (their T is never used: J_ii is not a pair term).
+    struct PairT { double c2[D], s2[D], del, rdel, tc[D], ts[D], td[D]; };
+    static CG_DEVI void pt_load(const double* pt, int e /* i n + k */, double c1, double c2c, PairT& p) {
+        const double* q = pt + (size_t)e * PFS;
 #pragma unroll
-        for (int bb = 0; bb < D; ++bb) { t.tc[bb] = -c1 * pf.s2[bb]; t.ts[bb] = c1 * pf.c2[bb]; t.td[bb] = c2c * pf.s2[bb] * t.rdel; }
+        for (int a = 0; a < D; ++a) { p.c2[a] = q[a]; p.s2[a] = q[D + a]; }
+        p.del = q[2 * D]; p.rdel = q[2 * D + 1];
+#pragma unroll
+        for (int a = 0; a < D; ++a) { p.tc[a] = -c1 * p.s2[a]; p.ts[a] = c1 * p.c2[a]; p.td[a] = c2c * (p.s2[a] * p.rdel); }
+    }
+    // fills the pair table from the half-angle tables of primal() (sh, ch)
+    static CG_DEVI void pt_build(const CgBlk& b, const double* sh, const double* ch, int n, unsigned mn, double* pt) {
+        for (int e = b.tid; e < n * n; e += b.nthr) {
+            const int i = cg_udiv(e, mn), k = e - i * n;
+            double* q = pt + (size_t)e * PFS;
+#if defined(__HIP_DEVICE_COMPILE__)
+            typename F::PF6 f; F::own_pair(sh, ch, i, k, true, f);          // v_rsq_f64-based sqrt / reciprocal, as the sampler
+#pragma unroll
+            for (int a = 0; a < D; ++a) { q[a] = f.c2[a]; q[D + a] = f.s2[a]; }
+            q[2 * D] = f.del; q[2 * D + 1] = f.rdel;
+#else
+            typename F::PairF f; F::pairfeat(sh, ch, i, k, f);
+#pragma unroll
+            for (int a = 0; a < D; ++a) { q[a] = f.c2[a]; q[D + a] = f.s2[a]; }
+            q[2 * D] = f.del; q[2 * D + 1] = i == k ? 0.0 : 1.0 / f.del;
+#endif
+        }
     }
 
     // ------------------------------------------------------------------------------------------------------
@@ -180,6 +211,7 @@ struct CgLap {
         if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
 #endif
         F::primal(b, th, (const double*)x, n, L, da, o, wf);
+        pt_build(b, da + o.sh, da + o.ch, n, l.mn, mem.a + l.pt);          // (read after the barriers of the Jacobian assembly)
         F::jacobian(b, th, n, L, da, o, wf);
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
         bool inverted = false;
@@ -292,34 +324,39 @@ struct CgLap {
         const int N = n * D;
         const CgFastLds& o = l.o;
         const double* da = mem.a + l.da;
-        const double *sh = da + o.sh, *ch = da + o.ch, *sg1 = da + o.sg1, *sg2 = da + o.sg2, *U = da + o.U, *V = da + o.V,
-                     *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
+        const double *sg1 = da + o.sg1, *sg2 = da + o.sg2, *U = da + o.U, *V = da + o.V, *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
+        const double* PT = mem.a + l.pt;
         const double* Jinv = mem.p + l.Jinv;
         double *Jhat = mem.a + l.Jhat, *Upb = mem.a + l.Upb, *Vb = mem.a + l.Vb, *Bb = mem.a + l.Bb, *Gb = mem.a + l.Gb, *sg1b = mem.a + l.sg1b,
                *sg2b = mem.a + l.sg2b, *Ub = mem.a + l.Ub, *Rb = mem.a + l.Rb, *u2b = mem.a + l.u2b, *u1b = mem.a + l.u1b, *s1b = mem.a + l.s1b,
                *m1b = mem.a + l.m1b, *gbb = mem.a + l.gbb, *su2 = mem.a + l.su2, *m0b = mem.a + l.m0b, *rbar = mem.a + l.rbar, *xbar = mem.p + l.xbar;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        const unsigned mn = l.mn, mN = l.mN;
 
-        // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii (k != i),  Jbar = 1/2 J^-T
+        // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii (k != i),  Jbar = 1/2 J^-T;  Jhat_ii = 0
         for (int e = b.tid; e < N * N; e += b.nthr) {
-            const int r = e / N, c = e - r * N, i = r / D, k = c / D, bb = c - k * D;
+            const int r = cg_udiv(e, mN), c = e - r * N, i = r / D, k = c / D, bb = c - k * D;
             Jhat[e] = (i == k) ? 0.0 : 0.5 * (Jinv[c * N + r] - Jinv[(i * D + bb) * N + r]);
         }
         b.sync();
-        // (J5) adjoints that are sums over k for fixed i
+        // (J5) adjoints that are sums over k for fixed i (the k = i terms vanish with Jhat_ii = 0)
         for (int e = b.tid; e < N * P; e += b.nthr) {              // Upbar_i[a][f] = -sum_k sum_b Jhat_ik[a][b] T_ik[f][b]
             const int r = e / P, f = e - r * P, i = r / D;
+            const double* jr = Jhat + (size_t)r * N; const double* pr = PT + (size_t)i * n * PFS;
             double acc = 0;
-            for (int k = 0; k < n; ++k) {
-                if (k == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+            if (f < 2 * D) {                                        // cos / sin feature of direction bb: T = -c1 s2 / c1 c2
+                const int bb = f < D ? f : f - D, off = f < D ? D + bb : bb;
+                for (int k = 0; k < n; ++k) acc += jr[k * D + bb] * pr[k * PFS + off];
+                acc *= f < D ? c1 : -c1;
+            } else {                                                // norm feature: T_b = c2c s2_b / del
+                for (int k = 0; k < n; ++k) {
+                    double t = 0;
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) {
-                    const double tv = (f == bb) ? t.tc[bb] : (f == D + bb) ? t.ts[bb] : (f == 2 * D) ? t.td[bb] : 0.0;
-                    acc -= Jhat[r * N + k * D + bb] * tv;
+                    for (int bb = 0; bb < D; ++bb) t += jr[k * D + bb] * pr[k * PFS + D + bb];
+                    acc += t * pr[k * PFS + 2 * D + 1];
                 }
+                acc *= -c2c;
             }
             Upb[e] = acc;
         }
@@ -349,19 +386,18 @@ struct CgLap {
             for (int a = 0; a < D; ++a) vb[a] = 0;
             for (int k = 0; k < n; ++k) {
                 if (k == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
-                double u = bt + wt[2 * D] * pf.del, q[D];
+                PairT t; pt_load(PT, i * n + k, c1, c2c, t);
+                double u = bt + wt[2 * D] * t.del, q[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    u += wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
                     q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
                 }
                 const double sg = sigmoid_only(u);
 #pragma unroll
                 for (int a = 0; a < D; ++a)
 #pragma unroll
-                    for (int bb = 0; bb < D; ++bb) vb[a] -= Jhat[(i * D + a) * N + k * D + bb] * sg * q[bb];
+                    for (int bb = 0; bb < D; ++bb) vb[a] -= Jhat[(i * D + a) * N + k * D + bb] * (sg * q[bb]);
             }
 #pragma unroll
             for (int a = 0; a < D; ++a) Vb[(i * D + a) * HT + h] = vb[a];
@@ -374,23 +410,23 @@ struct CgLap {
 #pragma unroll
             for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
             const double w_d = th[F::o_W0 + 2 * D * HS + h];
+            double gp[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) gp[bb] = Gb[(p * HS + h) * D + bb];
             double sb = 0;
             for (int q = 0; q < n; ++q) {
                 if (q == p) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, p, q, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+                PairT t; pt_load(PT, p * n + q, c1, c2c, t);
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) {
-                    const double dG = (Gb[(p * HS + h) * D + bb] - Gb[(q * HS + h) * D + bb]) * rn * rn;
-                    sb += dG * (w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb]);
-                }
+                for (int bb = 0; bb < D; ++bb)
+                    sb += (gp[bb] - Gb[(q * HS + h) * D + bb]) * (w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb]);
             }
             double acc = 0;
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
                 for (int f = 0; f < P; ++f) acc += Upb[(p * D + a) * P + f] * U[(p * D + a) * HS + h] * th[F::o_W0 + f * HS + h];
-            sg1b[e] = sb + acc * rn;
+            sg1b[e] = sb * (rn * rn) + acc * rn;
         }
         for (int e = b.tid; e < N * HS; e += b.nthr) {             // Ubar_i[a][g]
             const int r = e / HS, g = e - r * HS, i = r / D;
@@ -462,14 +498,13 @@ struct CgLap {
         b.sync();
         // pair pass: adjoints of the features t0_ik (value: t0bar) and of their r-derivatives T_ik (Tc, Ts, Td), then rbar_ik
         for (int e = b.tid; e < n * n; e += b.nthr) {
-            const int i = e / n, k = e - i * n;
+            const int i = cg_udiv(e, mn), k = e - i * n;
             if (i == k) {
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) rbar[e * D + bb] = 0.0;
                 continue;
             }
-            typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-            TCol t; tcols(pf, c1, c2c, t);
+            PairT t; pt_load(PT, e, c1, c2c, t);
             double Jh[D][D];
 #pragma unroll
             for (int a = 0; a < D; ++a)
@@ -503,10 +538,10 @@ struct CgLap {
                 double wt[P];
 #pragma unroll
                 for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
-                double u = th[F::o_t0b + h] + wt[2 * D] * pf.del, q[D];
+                double u = th[F::o_t0b + h] + wt[2 * D] * t.del, q[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    u += wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
                     q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
                 }
                 const double sg = sigmoid_only(u), sgp = sg * (1.0 - sg);
@@ -536,8 +571,8 @@ struct CgLap {
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) {
                 double r = t0b[bb] * t.tc[bb] + t0b[D + bb] * t.ts[bb] + t0b[2 * D] * t.td[bb];
-                r += -c1 * c1 * (Tc[bb] * pf.c2[bb] + Ts[bb] * pf.s2[bb]);
-                r += t.rdel * (Td[bb] * pl2 * pf.c2[bb] - t.td[bb] * tdd);
+                r += -c1 * c1 * (Tc[bb] * t.c2[bb] + Ts[bb] * t.s2[bb]);
+                r += t.rdel * (Td[bb] * pl2 * t.c2[bb] - t.td[bb] * tdd);
                 rbar[e * D + bb] = r;
             }
         }
@@ -557,17 +592,122 @@ struct CgLap {
     //   lap sp(u) = sig(u) lap u + sig'(u) |grad u|^2
     // Pair features depend on r = x_i - x_j only: lap_x f(r) = 2 lap_r f, |grad_x f|^2 = 2 |grad_r f|^2.
     // ------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+    // |grad_x u2_i[h]|^2 on the matrix cores (spsize = tpsize = 16).  For one particle i the dense x-gradient of the last layer's
+    // pre-activations is  E_ik[h][b] = H_k[h][b] - (1/n) (A_i T_ik)[h][b] - (1/n) sum_g Wc[g][h] sig_t(u_ik[g]) q_ik[g][b]  (k != i),
+    // E_ii = -sum_k E_ik.  The last term is a (n x 16)(16 x 16) product per direction b: rows = partner particle k, K = hidden unit g
+    // of the two-particle stream, columns = h.  A operand sig q computed by the lane that feeds it (row k = lane & 15, g = 4 ks +
+    // (lane >> 4)), B operand -Wc / n held in registers for all i, the first two terms are the C operand.  A wave owns particle i:
+    // no barrier and no LDS round trip of sig q or E; sum_k |E_ik|^2 + |sum_k E_ik|^2 leaves the wave as 16 numbers.
+    static __device__ __forceinline__ void su2_mfma(const CgBlk& b, const double* th, int n, double rn, double c1, double c2c,
+                                                    const double* PT, const double* wt, const double* Am, const double* Hk, double* Su2) {
+        using d4 = typename F::d4_t;
+        const int lane = b.tid & 63, col = lane & 15, kq = lane >> 4, wave = b.tid >> 6, nw = b.nthr >> 6;
+        double wg[4][P + 1], bw[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int g = 4 * ks + kq;
+#pragma unroll
+            for (int f = 0; f <= P; ++f) wg[ks][f] = wt[g * (P + 1) + f];
+            bw[ks] = -rn * th[F::o_Wc + g * HS + col];
+        }
+        const int tiles = (n + 15) >> 4;
+        for (int i = wave; i < n; i += nw) {
+            double Ai[P];
+#pragma unroll
+            for (int f = 0; f < P; ++f) Ai[f] = Am[(i * HS + col) * P + f];
+            double ssq = 0.0, sm[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) sm[bb] = 0.0;
+            for (int kt = 0; kt < tiles; ++kt) {
+                d4 c[D];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                       // C operand: rows k = 16 kt + kq + 4 r of column h = col
+                    const int k = 16 * kt + kq + 4 * r;
+                    const bool ok = k < n && k != i;
+                    PairT t; pt_load(PT, i * n + (ok ? k : i), c1, c2c, t);
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb)
+                        c[bb][r] = ok ? Hk[((ok ? k : 0) * HS + col) * D + bb] - rn * (Ai[bb] * t.tc[bb] + Ai[D + bb] * t.ts[bb] + Ai[2 * D] * t.td[bb]) : 0.0;
+                }
+                const int ka = 16 * kt + col;                       // A operand: row k = 16 kt + col
+                const bool oka = ka < n && ka != i;
+                PairT ta; pt_load(PT, i * n + (oka ? ka : i), c1, c2c, ta);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    double u = wg[ks][0] + wg[ks][1 + 2 * D] * ta.del, q[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        u += wg[ks][1 + a] * ta.c2[a] + wg[ks][1 + D + a] * ta.s2[a];
+                        q[a] = wg[ks][1 + a] * ta.tc[a] + wg[ks][1 + D + a] * ta.ts[a] + wg[ks][1 + 2 * D] * ta.td[a];
+                    }
+                    const double sg = oka ? sigmoid_only(u) : 0.0;
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) c[bb] = F::mfma(sg * q[bb], bw[ks], c[bb]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) { ssq = fma(c[bb][r], c[bb][r], ssq); sm[bb] += c[bb][r]; }
+            }
+            // rows are spread over the four 16-lane groups of the wave (kq): fixed-order butterfly over kq
+            ssq += __shfl_xor(ssq, 16); ssq += __shfl_xor(ssq, 32);
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) { sm[bb] += __shfl_xor(sm[bb], 16); sm[bb] += __shfl_xor(sm[bb], 32); ssq = fma(sm[bb], sm[bb], ssq); }
+            if (kq == 0) Su2[i * HS + col] = ssq;
+        }
+    }
+    // A_i = Wa^T diag(sg1_i) W0^T (HS x P) and H_k = Wb^T G_k (HS x D) on the matrix cores: 4 MFMAs per particle / per 16 rows (k, b)
+    static __device__ __forceinline__ void am_hk_mfma(const CgBlk& b, const double* th, int n, const double* sg1, const double* G,
+                                                      double* Am, double* Hk) {
+        using d4 = typename F::d4_t;
+        const int lane = b.tid & 63, col = lane & 15, kq = lane >> 4, wave = b.tid >> 6, nw = b.nthr >> 6;
+        double wa[4], w0[4], wb[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int g = 4 * ks + kq;
+            wa[ks] = th[F::o_Wa + g * HS + col];                    // A[row h = col][k = g] = Wa[g][h] (times sg1_i[g])
+            w0[ks] = col < P ? th[F::o_W0 + col * HS + g] : 0.0;    // B[k = g][col f] = W0[f][g]
+            wb[ks] = th[F::o_Wb + g * HS + col];                    // B[k = g][col h] = Wb[g][h]
+        }
+        for (int i = wave; i < n; i += nw) {
+            d4 c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = F::mfma(wa[ks] * sg1[i * HS + 4 * ks + kq], w0[ks], c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (col < P) Am[(i * HS + kq + 4 * r) * P + col] = c[r];
+        }
+        const int N = n * D, tiles = (N + 15) >> 4;
+        for (int t = wave; t < tiles; t += nw) {
+            const int ra = 16 * t + col, ka = ra / D, ba = ra - ka * D;           // A row (k, b)
+            d4 c = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) c = F::mfma(ra < N ? G[F::iG(ka, 4 * ks + kq, ba)] : 0.0, wb[ks], c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = 16 * t + kq + 4 * r;
+                if (rr < N) Hk[((rr / D) * HS + col) * D + (rr % D)] = c[r];
+            }
+        }
+    }
+#endif
+
     template <bool AL>
     static CG_DEVI void forward_laplacian(const CgBlk& b, const double* __restrict__ th, int n, double L, const Mem<AL>& mem,
                                           const Lay& l, double& q_re, double& q_im) {
         const CgFastLds& o = l.o;
         const double* da = mem.a + l.da;
-        const double *sh = da + o.sh, *ch = da + o.ch, *sg1 = da + o.sg1, *sg2 = da + o.sg2, *G = da + o.G;
+        const double *sg1 = da + o.sg1, *sg2 = da + o.sg2, *G = da + o.G;
+        const double* PT = mem.a + l.pt;
         const double* gz = mem.p + l.gz;
         double *Lm0 = mem.a + l.Lm0, *gu1 = mem.a + l.gu1, *Ls1 = mem.a + l.Ls1, *Lm1 = mem.a + l.Lm1, *Lgb = mem.a + l.Lgb, *Am = mem.a + l.Am,
-               *Hk = mem.a + l.Hk, *SQ = mem.a + l.SQ, *Er = mem.a + l.Er, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
+               *Hk = mem.a + l.Hk, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
+        bool mfma_path = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (HS == 16 && HT == 16) mfma_path = true;
+#endif
 
         // pair pass, item (i,h): lap m1_i[h], lap m0_i[f], |grad u1_i[h]|^2
         for (int e = b.tid; e < n * HM; e += b.nthr) {
@@ -580,18 +720,17 @@ struct CgLap {
             double acc = 0.0, raw = 0.0;
             for (int j = 0; j < n; ++j) {
                 if (j == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, j, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+                PairT t; pt_load(PT, i * n + j, c1, c2c, t);
                 double l0d = 0.0;                                   // lap_r of the norm feature
 #pragma unroll
-                for (int a = 0; a < D; ++a) l0d += pl2 * pf.c2[a] - t.td[a] * t.td[a];
+                for (int a = 0; a < D; ++a) l0d += pl2 * t.c2[a] - t.td[a] * t.td[a];
                 l0d *= t.rdel;
                 if (do_t) {
-                    double u = bt + wt[2 * D] * pf.del, lu = wt[2 * D] * l0d, gsq = 0.0;
+                    double u = bt + wt[2 * D] * t.del, lu = wt[2 * D] * l0d, gsq = 0.0;
 #pragma unroll
                     for (int a = 0; a < D; ++a) {
-                        u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
-                        lu -= c1 * c1 * (wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a]);
+                        const double wf = wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
+                        u += wf; lu -= c1 * c1 * wf;
                         const double q = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
                         gsq += q * q;
                     }
@@ -601,7 +740,7 @@ struct CgLap {
                 if (h < P) {
                     double fv = l0d;
 #pragma unroll
-                    for (int a = 0; a < D; ++a) { if (h == a) fv = -c1 * c1 * pf.c2[a]; if (h == D + a) fv = -c1 * c1 * pf.s2[a]; }
+                    for (int a = 0; a < D; ++a) { if (h == a) fv = -c1 * c1 * t.c2[a]; if (h == D + a) fv = -c1 * c1 * t.s2[a]; }
                     raw += 2.0 * fv;
                 }
             }
@@ -619,8 +758,7 @@ struct CgLap {
             for (int a = 0; a < D; ++a) sq[a] = 0.0;
             for (int k = 0; k < n; ++k) {
                 if (k == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+                PairT t; pt_load(PT, i * n + k, c1, c2c, t);
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) {
                     const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
@@ -632,19 +770,25 @@ struct CgLap {
             gu1[e] = ssq * rn * rn;
         }
         // per-particle factors of the dense x-gradient of u2:  A_i = Wa^T diag(sg1_i) W0^T (HS x P),  H_k = Wb^T G_k (HS x D)
-        for (int e = b.tid; e < n * HS * P; e += b.nthr) {
-            const int i = e / (HS * P), r = e - i * HS * P, h = r / P, f = r - h * P;
-            double acc = 0;
+        if (mfma_path) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (HS == 16 && HT == 16) am_hk_mfma(b, th, n, sg1, G, Am, Hk);
+#endif
+        } else {
+            for (int e = b.tid; e < n * HS * P; e += b.nthr) {
+                const int i = e / (HS * P), r = e - i * HS * P, h = r / P, f = r - h * P;
+                double acc = 0;
 #pragma unroll
-            for (int g = 0; g < HS; ++g) acc += th[F::o_Wa + g * HS + h] * sg1[i * HS + g] * th[F::o_W0 + f * HS + g];
-            Am[e] = acc;
-        }
-        for (int e = b.tid; e < n * HS * D; e += b.nthr) {
-            const int k = e / (HS * D), r = e - k * HS * D, h = r / D, bb = r - h * D;
-            double acc = 0;
+                for (int g = 0; g < HS; ++g) acc += th[F::o_Wa + g * HS + h] * sg1[i * HS + g] * th[F::o_W0 + f * HS + g];
+                Am[e] = acc;
+            }
+            for (int e = b.tid; e < n * HS * D; e += b.nthr) {
+                const int k = e / (HS * D), r = e - k * HS * D, h = r / D, bb = r - h * D;
+                double acc = 0;
 #pragma unroll
-            for (int g = 0; g < HS; ++g) acc += th[F::o_Wb + g * HS + h] * G[F::iG(k, g, bb)];
-            Hk[e] = acc;
+                for (int g = 0; g < HS; ++g) acc += th[F::o_Wb + g * HS + h] * G[F::iG(k, g, bb)];
+                Hk[e] = acc;
+            }
         }
         b.sync();
         for (int e = b.tid; e < n * HS; e += b.nthr) {             // lap s1
@@ -655,71 +799,82 @@ struct CgLap {
             const double g1 = sg1[e];
             Ls1[e] = g1 * lu + g1 * (1.0 - g1) * gu1[e];
         }
-        b.sync();
-        for (int h = b.tid; h < HS; h += b.nthr) {
-            double a = 0;
-            for (int i = 0; i < n; ++i) a += Ls1[i * HS + h];
-            Lgb[h] = a * rn;
-        }
-        // |grad_x u2_i[h]|^2, one particle i at a time:  E_ik[h][b] = d u2_i[h] / d x_kb  (k != i),  E_ii = -sum_k E_ik
+        // |grad_x u2_i[h]|^2:  E_ik[h][b] = d u2_i[h] / d x_kb  (k != i),  E_ii = -sum_k E_ik
         //   E_ik = -(1/n) A_i T_ik + H_k - (1/n) Wc^T diag(sig_t(u_ik)) Wt^T T_ik
-        for (int i = 0; i < n; ++i) {
-            for (int e = b.tid; e < n * HT; e += b.nthr) {          // SQ[k][g][b] = sig_t(u_ik[g]) q_ik[g][b]
-                const int k = e / HT, g = e - k * HT;
-                if (k == i) {
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = 0.0;
-                    continue;
-                }
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
-                const double wd = th[F::o_t0w + 2 * D * HT + g];
-                double u = th[F::o_t0b + g] + wd * pf.del, q[D];
-#pragma unroll
-                for (int a = 0; a < D; ++a) {
-                    const double wc = th[F::o_t0w + a * HT + g], ws_ = th[F::o_t0w + (D + a) * HT + g];
-                    u += wc * pf.c2[a] + ws_ * pf.s2[a];
-                    q[a] = wc * t.tc[a] + ws_ * t.ts[a] + wd * t.td[a];
-                }
-                const double sg = sigmoid_only(u);
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = sg * q[bb];
-            }
-            b.sync();
-            for (int e = b.tid; e < n * HS; e += b.nthr) {
-                const int k = e / HS, h = e - k * HS;
-                if (k == i) {
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = 0.0;
-                    continue;
-                }
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
-                const double* A = Am + ((size_t)i * HS + h) * P;
-                double ev[D];
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) ev[bb] = Hk[e * D + bb] - rn * (A[bb] * t.tc[bb] + A[D + bb] * t.ts[bb] + A[2 * D] * t.td[bb]);
-                for (int g = 0; g < HT; ++g) {
-                    const double wc = rn * th[F::o_Wc + g * HS + h];
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) ev[bb] -= wc * SQ[(k * HT + g) * D + bb];
-                }
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = ev[bb];
-            }
+        if (mfma_path) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (HS == 16 && HT == 16) su2_mfma(b, th, n, rn, c1, c2c, PT, da + o.wt, Am, Hk, Su2);
+#endif
             b.sync();
             for (int h = b.tid; h < HS; h += b.nthr) {
-                double ssq = 0.0, sm[D];
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) sm[bb] = 0.0;
-                for (int k = 0; k < n; ++k)
-#pragma unroll
-                    for (int bb = 0; bb < D; ++bb) { const double v = Er[(k * HS + h) * D + bb]; ssq += v * v; sm[bb] += v; }
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) ssq += sm[bb] * sm[bb];
-                Su2[i * HS + h] = ssq;
+                double a = 0;
+                for (int i = 0; i < n; ++i) a += Ls1[i * HS + h];
+                Lgb[h] = a * rn;
             }
-            // (the next particle's SQ pass is separated from this Er read by its own barrier pair)
+        } else {
+            double *SQ = mem.a + l.SQ, *Er = mem.a + l.Er;
+            b.sync();
+            for (int h = b.tid; h < HS; h += b.nthr) {
+                double a = 0;
+                for (int i = 0; i < n; ++i) a += Ls1[i * HS + h];
+                Lgb[h] = a * rn;
+            }
+            for (int i = 0; i < n; ++i) {                           // one particle i at a time
+                for (int e = b.tid; e < n * HT; e += b.nthr) {      // SQ[k][g][b] = sig_t(u_ik[g]) q_ik[g][b]
+                    const int k = e / HT, g = e - k * HT;
+                    if (k == i) {
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = 0.0;
+                        continue;
+                    }
+                    PairT t; pt_load(PT, i * n + k, c1, c2c, t);
+                    const double wd = th[F::o_t0w + 2 * D * HT + g];
+                    double u = th[F::o_t0b + g] + wd * t.del, q[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double wc = th[F::o_t0w + a * HT + g], ws_ = th[F::o_t0w + (D + a) * HT + g];
+                        u += wc * t.c2[a] + ws_ * t.s2[a];
+                        q[a] = wc * t.tc[a] + ws_ * t.ts[a] + wd * t.td[a];
+                    }
+                    const double sg = sigmoid_only(u);
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) SQ[e * D + bb] = sg * q[bb];
+                }
+                b.sync();
+                for (int e = b.tid; e < n * HS; e += b.nthr) {
+                    const int k = e / HS, h = e - k * HS;
+                    if (k == i) {
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = 0.0;
+                        continue;
+                    }
+                    PairT t; pt_load(PT, i * n + k, c1, c2c, t);
+                    const double* A = Am + ((size_t)i * HS + h) * P;
+                    double ev[D];
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) ev[bb] = Hk[e * D + bb] - rn * (A[bb] * t.tc[bb] + A[D + bb] * t.ts[bb] + A[2 * D] * t.td[bb]);
+                    for (int g = 0; g < HT; ++g) {
+                        const double wc = rn * th[F::o_Wc + g * HS + h];
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) ev[bb] -= wc * SQ[(k * HT + g) * D + bb];
+                    }
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) Er[e * D + bb] = ev[bb];
+                }
+                b.sync();
+                for (int h = b.tid; h < HS; h += b.nthr) {
+                    double ssq = 0.0, sm[D];
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) sm[bb] = 0.0;
+                    for (int k = 0; k < n; ++k)
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) { const double v = Er[(k * HS + h) * D + bb]; ssq += v * v; sm[bb] += v; }
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) ssq += sm[bb] * sm[bb];
+                    Su2[i * HS + h] = ssq;
+                }
+                // (the next particle's SQ pass is separated from this Er read by its own barrier pair)
+            }
         }
         b.sync();
         for (int e = b.tid; e < n * HS; e += b.nthr) {             // lap s2 = lap s1 + sg2 lap u2 + sg2' |grad u2|^2
