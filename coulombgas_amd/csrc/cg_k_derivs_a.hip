@@ -3,6 +3,7 @@
 #include "cg_host.hpp"
 #include "cg_derivs.hpp"
 #include "cg_lap.hpp"
+#include "cg_score.hpp"
 
 #define CG_UNIT_CONFIGS(X) CG_FAST_CONFIGS_A(X)
 #define CG_UNIT_NAME(f) cg_derivs_a_##f
@@ -12,6 +13,7 @@ int cg_derivs_b_grad_lap(cg_ctx* c, int nt, int grid, const CgDev& m, const doub
                          double* grad, double* lap);
 int cg_derivs_b_param_vjp(cg_ctx* c, int nt, int grid, const CgDev& m, const double* x, const int* sidx, int B, const double* w_re,
                           const double* w_im, double* partial, double* score);
+int cg_derivs_b_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, double* score);
 
 // deterministic second-stage reduction of per-workgroup partial gradients: out[p] = sum_g partial[g][p]
 __global__ void k_reduce_rows(const double* __restrict__ partial, int rows, int P, double* __restrict__ out) {
@@ -243,10 +245,28 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
     }
     const int nt = 256;
     const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
-    double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
-    if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
     const CgDev m = make_dev(c);
     bool launched = false;
+    if (c->fast) {
+        // second-generation score kernel (cg_score.hpp) where the system fits its LDS plan: the scores go to the caller's buffer, the
+        // resident buffer or -- for a plain theta-VJP -- a temporary, and the weighted sum is the sliced GEMV over them
+        double* sc = (double*)asc.dev;
+        if (!sc && g_theta) {
+            sc = (double*)arena_take(c, asc.bytes);
+            if (!sc) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
+        }
+        if (sc) {
+            if ((rc = cg_derivs_a_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+            if (rc == 0 && (rc = cg_derivs_b_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+            if (rc == 1) {
+                launched = true;
+                if (g_theta && (rc = score_reduce(c, sc, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
+                g_theta = nullptr;                         // (done: skips the partial-row reduction of the first-generation kernel below)
+            }
+        }
+    }
+    double* partial = (g_theta && !launched) ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
+    if (g_theta && !launched && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
     if (!c->fast) {       // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
         if ((rc = cg_gen_run_param_vjp(c, grid, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev,
                                        partial, (double*)asc.dev))) return rc;

@@ -2,6 +2,7 @@
 #include "cg_host.hpp"
 #include "cg_derivs.hpp"
 #include "cg_lap.hpp"
+#include "cg_score.hpp"
 
 #define CG_UNIT_CONFIGS(X) CG_FAST_CONFIGS_B(X)
 #define CG_UNIT_NAME(f) cg_derivs_b_##f

@@ -22,6 +22,19 @@
 // AL = true and every access is a ds_ instruction.
 #pragma once
 #include "cg_flow_fast.hpp"
+// unroll factors of the pair loops (independent sigmoid chains per trip hide the LDS / transcendental latencies at 2 waves per SIMD)
+#ifndef CG_UNR_K
+#define CG_UNR_K 2
+#endif
+#ifndef CG_UNR_H
+#define CG_UNR_H 2
+#endif
+#ifndef CG_UNR_Q
+#define CG_UNR_Q 2
+#endif
+#ifndef CG_UNR_G
+#define CG_UNR_G 4
+#endif
 
 template <int D, int HS, int HT>
 struct CgLap {
@@ -47,7 +60,7 @@ struct CgLap {
         // P
         int red, x, gz, xbar, Jinv, Ta, Kd, TaKd_in_P;
         // A
-        int da, pt, Jc, Dc, Dinv, perm, C;
+        int da, pt, kocc, Jc, Dc, Dinv, perm, C;
         int Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, u2b, u1b, s1b, m1b, gbb, su2, m0b, rbar;
         int Lm0, gu1, Ls1, Lm1, Lgb, Am, Hk, SQ, Er, Su2, Ls2;
         // B
@@ -97,6 +110,7 @@ struct CgLap {
         // pair table: the features of every ordered pair (i, k), computed ONCE per walker in the set-up; every pair loop of the
         // reverse sweep and of the forward Laplacian reads a row of it instead of recomputing ~90 instructions per pair
         l.pt = take((size_t)n * n * PFS);
+        l.kocc = take(N);                                   // wave vectors of the walker's occupied orbitals (set-up, Slater part)
         const size_t A1 = t;
         // R3: J, Slater matrix (dead after the Slater part);  R2: primal temporaries;  then the set-up scratch
         o.J = take(NN); o.Dm = take(nn2); o.lus = take(2);
@@ -203,22 +217,32 @@ struct CgLap {
         const int N = n * D;
         const CgFastLds& o = l.o;
         double* da = mem.a + l.da; double* x = mem.p + l.x;
-        for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
+        double* kocc = mem.a + l.kocc;       // k_j of the occupied orbitals, staged once: the T^a / K^ab loops below would chase
+        for (int e = b.tid; e < N; e += b.nthr) {                  // state_idx -> orbital table through global memory per term
+            x[e] = xg[e];
+            const int j = e / D;
+            kocc[e] = spk[(size_t)sidx[j] * D + (e - j * D)];
+        }
         b.sync();
         const typename F::WFrag* wf = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
         typename F::WFrag wfrag;
         if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
 #endif
+        CG_STAMP_START(25)
         F::primal(b, th, (const double*)x, n, L, da, o, wf);
+        CG_STAMP_END(25)
+        CG_STAMP_START(26)
         pt_build(b, da + o.sh, da + o.ch, n, l.mn, mem.a + l.pt);          // (read after the barriers of the Jacobian assembly)
         F::jacobian(b, th, n, L, da, o, wf);
+        CG_STAMP_END(26)
+        CG_STAMP_START(27)
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
         bool inverted = false;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (N <= 32 && n <= 16 && b.nthr >= 128 && N * N + 2 * n * n >= 128) {      // (the Jc + Dc slots are the 128-double scratch)
             // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (no barriers, J and D intact)
-            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
             const int wave = b.tid >> 6;
             if (wave == 0) {
                 if (N == 26) cg_wave_inverse_real<26>(da + o.J, N, N, Jinv, N, Jc);
@@ -236,19 +260,22 @@ struct CgLap {
             for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
             b.sync();
             (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
             for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
             b.sync();
             double la, ar;
             cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
         }
+        CG_STAMP_END(27)
+        CG_STAMP_START(28)
         const double* Dm = da + o.Dm;
         double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd; double* gz = mem.p + l.gz;
-        for (int e = b.tid; e < D * n * n; e += b.nthr) {            // T^a = D diag(i k^a) D^-1
-            const int a = e / (n * n), r = e - a * n * n, i = r / n, q = r - i * n;
+        const int nn = n * n;
+        for (int e = b.tid; e < D * nn; e += b.nthr) {               // T^a = D diag(i k^a) D^-1
+            const int a = e >= nn ? (D > 2 && e >= 2 * nn ? 2 : 1) : 0, r = e - a * nn, i = cg_udiv(r, l.mn), q = r - i * n;
             double re = 0, im = 0;
             for (int j = 0; j < n; ++j) {
-                const double ka = spk[(size_t)sidx[j] * D + a];
+                const double ka = kocc[j * D + a];
                 const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + q)], Dinv[2 * (j * n + q) + 1]});
                 re += -ka * p.im; im += ka * p.re;
             }
@@ -256,16 +283,17 @@ struct CgLap {
             if (i == q) { gz[2 * (i * D + a)] = re; gz[2 * (i * D + a) + 1] = im; }   // g_ia = T^a_ii
         }
         for (int e = b.tid; e < D * D * n; e += b.nthr) {            // diag of K^ab = D diag(-k^a k^b) D^-1
-            const int a = e / (D * n), r = e - a * D * n, bb = r / n, i = r - bb * n;
+            const int i = e / (D * D), r = e - i * D * D, a = r / D, bb = r - a * D;
             double re = 0, im = 0;
             for (int j = 0; j < n; ++j) {
-                const double kk = -spk[(size_t)sidx[j] * D + a] * spk[(size_t)sidx[j] * D + bb];
+                const double kk = -kocc[j * D + a] * kocc[j * D + bb];
                 const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
                 re += kk * p.re; im += kk * p.im;
             }
-            Kd[2 * e] = re; Kd[2 * e + 1] = im;
+            Kd[2 * ((a * D + bb) * n + i)] = re; Kd[2 * ((a * D + bb) * n + i) + 1] = im;
         }
         b.sync();
+        CG_STAMP_END(28)
     }
 
     // ------------------------------------------------------------------------------------------------------
@@ -384,6 +412,7 @@ struct CgLap {
             double vb[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) vb[a] = 0;
+#pragma unroll CG_UNR_K
             for (int k = 0; k < n; ++k) {
                 if (k == i) continue;
                 PairT t; pt_load(PT, i * n + k, c1, c2c, t);
@@ -414,6 +443,7 @@ struct CgLap {
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) gp[bb] = Gb[(p * HS + h) * D + bb];
             double sb = 0;
+#pragma unroll CG_UNR_Q
             for (int q = 0; q < n; ++q) {
                 if (q == p) continue;
                 PairT t; pt_load(PT, p * n + q, c1, c2c, t);
@@ -524,6 +554,7 @@ struct CgLap {
                 }
                 Tc[bb] = c; Ts[bb] = s; Td[bb] = d;
             }
+#pragma unroll CG_UNR_G
             for (int g = 0; g < HS; ++g) {                          // G part: q0bar_ik[g][b] = sg1_i[g] (Gbar_i - Gbar_k)[g][b] / n^2
                 const double s1g = sg1[i * HS + g] * rn * rn;
 #pragma unroll
@@ -534,6 +565,7 @@ struct CgLap {
                     Td[bb] += th[F::o_W0 + 2 * D * HS + g] * q0b;
                 }
             }
+#pragma unroll CG_UNR_H
             for (int h = 0; h < HT; ++h) {
                 double wt[P];
 #pragma unroll
@@ -718,6 +750,7 @@ struct CgLap {
             for (int f = 0; f < P; ++f) wt[f] = do_t ? th[F::o_t0w + f * HT + h] : 0.0;
             if (do_t) bt = th[F::o_t0b + h];
             double acc = 0.0, raw = 0.0;
+#pragma unroll CG_UNR_K
             for (int j = 0; j < n; ++j) {
                 if (j == i) continue;
                 PairT t; pt_load(PT, i * n + j, c1, c2c, t);
@@ -756,6 +789,7 @@ struct CgLap {
             double ssq = 0.0, sq[D];
 #pragma unroll
             for (int a = 0; a < D; ++a) sq[a] = 0.0;
+#pragma unroll CG_UNR_Q
             for (int k = 0; k < n; ++k) {
                 if (k == i) continue;
                 PairT t; pt_load(PT, i * n + k, c1, c2c, t);

@@ -129,6 +129,15 @@ class EmulEngine:
         assert lib().emu_param_vjp(*self._args(), _p(s), _p(xb), B, None, None, None, _p(sc)) == 0
         return (sc[..., 0] + 1j * sc[..., 1]).reshape(lead + (self.P,))
 
+    def quantum_score2(self, x, sidx):
+        """second-generation score code (csrc/cg_score.hpp: the small-n kernel of the GPU library)"""
+        xb, lead = self._xb(x)
+        B = xb.shape[0]
+        s = np.ascontiguousarray(sidx, dtype=np.int32).reshape(B, self.n)
+        sc = np.empty((B, self.P, 2))
+        assert lib().emu_scores2(*self._args(), _p(s), _p(xb), B, _p(sc)) == 0
+        return (sc[..., 0] + 1j * sc[..., 1]).reshape(lead + (self.P,))
+
     def quantum_fisher(self, x, sidx):
         sc = self.quantum_score(x, sidx).reshape(-1, self.P)
         return (sc.conj().T @ sc).real / sc.shape[0], sc.mean(axis=0)

@@ -94,6 +94,29 @@ extern "C" int emu_param_vjp(int n, int dim, int hs, int ht, double L, const dou
     return -1;
 }
 
+// ---- per-sample scores, second generation (cg_score.hpp) on the host shim ----
+#include "../../coulombgas_amd/csrc/cg_score.hpp"
+template <int D, int HS, int HT>
+static int emu_scores2_t(int n, double L, const double* theta, const double* sp_indices, int M, const int* sidx,
+                         const double* x, int B, double* score) {
+    using G = CgScore<D, HS, HT>;
+    const auto lay = G::layout(n, 1, (size_t)1 << 30);
+    std::vector<double> lds(lay.total + 8), spk((size_t)M * D);
+    for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);
+    CgBlk b{0, 1};
+    memcpy(lds.data() + lay.th, theta, sizeof(double) * G::NP);
+    for (int w = 0; w < B; ++w)
+        G::scores(b, lds.data() + lay.th, x + (size_t)w * n * D, spk.data(), sidx + (size_t)w * n, n, L, score + (size_t)w * G::NP * 2, lds.data(), lay);
+    return 0;
+}
+extern "C" int emu_scores2(int n, int dim, int hs, int ht, double L, const double* theta, const double* sp_indices, int M,
+                           const int* sidx, const double* x, int B, double* score) {
+#define CG_X(D, HS, HT) if (dim == D && hs == HS && ht == HT) { if (HS != 16 || HT != 16) return -2; return emu_scores2_t<D, HS, HT>(n, L, theta, sp_indices, M, sidx, x, B, score); }
+    CG_FAST_CONFIGS(CG_X)
+#undef CG_X
+    return -1;
+}
+
 // ---- sampler and Ewald on the host shim (supplied noise only) ----
 #include "../../coulombgas_amd/csrc/cg_ewald.hpp"
 

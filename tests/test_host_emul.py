@@ -140,3 +140,18 @@ def test_grad_laplacian_memory_placements(budget):
     for mode, gk, lk in ((0, "grad", "lap_exact"), (1, "grad_hutch", "lap_hutch"), (2, "grad_split", "lap_split")):
         gr, lp = eng.grad_laplacian(g["x"], g["state_idx"], mode, g["v"])
         assert rel(gr, g[gk]) < 1e-11 and rel(lp, g[lk]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["golden_n7_d3.npz", "golden_n13_d2.npz"])
+def test_second_generation_scores_vs_golden(name):
+    """csrc/cg_score.hpp (the score kernel of the small systems: both parts in one sweep, pair table, planned LDS lifetimes) on the
+    host shim: its per-sample scores reproduce the oracle's theta-VJP of the golden vectors and the first-generation sweep."""
+    g = np.load(GOLDEN + "/" + name)
+    n, dim = int(g["n"]), int(g["dim"])
+    eng = EmulEngine(n, dim, 2, 16, 16, float(g["L"]), g["sp_indices"]); eng.set_params(g["theta"])
+    x, s = g["x"], g["state_idx"]
+    S2 = eng.quantum_score2(x, s)
+    vjp = (g["w_re"][:, None] * S2.real + g["w_im"][:, None] * S2.imag).sum(axis=0)
+    assert np.abs(vjp - g["vjp"]).max() < 1e-10 * np.abs(g["vjp"]).max()
+    S1 = eng.quantum_score(x, s)
+    assert np.abs(S2 - S1).max() < 1e-11 * np.abs(S1).max()

@@ -10,6 +10,8 @@ from coulombgas_amd.engine import Engine
 from coulombgas_amd import _lib
 NAMES = {20: "set-up (primal, J, J^-1, D^-1, T, K)", 21: "Slater part (J^T g, tr J^T H J)", 22: "reverse sweep (xbar)",
          23: "forward Laplacian", 24: "jet pass(es)"}
+SUB = {25: "set-up: x, k_occ, primal", 26: "set-up: pair table + Jacobian assembly", 27: "set-up: Slater matrix + both inverses",
+       28: "set-up: T^a, diag K^ab, g"}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
@@ -29,3 +31,6 @@ print("n=%d B=%d mode=%d: wave-cycles per walker by phase (4 waves per workgroup
 for k, nm in NAMES.items():
     print("  %2d %-36s %10.0f  %5.1f %%" % (k, nm, cyc[k] / B / 4, 100 * cyc[k] / tot))
 print("  total %.0f cycles per walker per wave" % (tot / B / 4))
+for k, nm in SUB.items():
+    if cyc[k]:
+        print("  %2d %-44s %10.0f  %5.1f %% of the kernel" % (k, nm, cyc[k] / B / 4, 100 * cyc[k] / tot))
