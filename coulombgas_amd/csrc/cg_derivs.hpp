@@ -12,10 +12,14 @@
 // kernel runs once per optimisation step, not per Metropolis step).
 #pragma once
 #include "cg_flow_fast.hpp"
+#include "cg_lap.hpp"
 
 template <int D, int HS, int HT>
 struct CgDerivs {
     using F = CgFast<D, HS, HT>;
+    using LP = CgLap<D, HS, HT>;
+    using PairT = typename LP::PairT;
+    static constexpr int PFS = LP::PFS;
     static constexpr int P = F::P;
     static constexpr int NP = F::NPARAM;
 
@@ -38,7 +42,7 @@ struct CgDerivs {
     }
     static size_t adj_doubles(int n) { return adj_layout(n).total; }
     struct Ws {   // offsets in doubles into the per-workgroup workspace
-        size_t da, x, Jc, Jinv, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, total;
+        size_t da, x, Jc, Jinv, Dc, Dinv, Ta, Kd, gz, zbar, Jbar, perm, adj, gw, pt, kocc, total;
     };
     static Ws ws_layout(int n) {
         const size_t N = (size_t)n * D;
@@ -54,22 +58,27 @@ struct CgDerivs {
         w.perm = take(N + 42);
         w.adj = take(adj_doubles(n));
         w.gw = take(NP);
+        w.pt = take((size_t)n * n * PFS);          // pair table (CgLap::pt_build)
+        w.kocc = take(N);
         w.total = t;
         return w;
     }
     // vjp_fast / vjp_da: LDS scratch of the theta-VJP kernel (doubles; 0 = none) and whether the primal arena lives there.
-    struct Layout { Ws w; Adj a; CgFastLds o; int vjp_fast; int vjp_da; };
+    struct Layout { Ws w; Adj a; CgFastLds o; int vjp_fast; int vjp_da; int stage; unsigned mn, mN; };
     static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
     static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
-    static Layout layout(int n, int nthr = 256) {
+    static CG_HD size_t stage_doubles(int n) { const size_t N = (size_t)n * D; return ((N * N + 1) & ~(size_t)1) + ((4 * N + 1) & ~(size_t)1) + 64 + ((N + 1) / 2 + 1 & ~(size_t)1); }
+    static Layout layout(int n, int nthr = 256, size_t lds_max_bytes = VJP_LDS_MAX_BYTES) {
         Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
+        l.mn = cg_div_magic((unsigned)n); l.mN = cg_div_magic((unsigned)(n * D));
         const size_t base = CG_TAB_DOUBLES + lds_doubles(n, nthr), inv = inv_scratch_doubles(n), NN = (size_t)n * D * n * D;
-        l.vjp_fast = 0; l.vjp_da = 0;
-        if (sizeof(double) * (base + l.o.total + inv - NN) <= VJP_LDS_MAX_BYTES) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
-        else if (sizeof(double) * (base + inv) <= VJP_LDS_MAX_BYTES) l.vjp_fast = (int)inv;
+        l.vjp_fast = 0; l.vjp_da = 0; l.stage = 0;
+        if (sizeof(double) * (base + l.o.total + inv - NN) <= lds_max_bytes) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
+        else if (sizeof(double) * (base + inv) <= lds_max_bytes) l.vjp_fast = (int)inv;
+        else if (sizeof(double) * (base + stage_doubles(n)) <= lds_max_bytes) l.stage = (int)stage_doubles(n);   // in-place inverses on an LDS copy
         return l;
     }
-    static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)l.vjp_fast; }
+    static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)(l.vjp_fast ? l.vjp_fast : l.stage); }
     static size_t ws_doubles(int n) { return ws_layout(n).total; }
     static CG_HD size_t lds_doubles(int n, int nthr) { (void)n; return (size_t)nthr + 16; }
 
@@ -79,7 +88,8 @@ struct CgDerivs {
     static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                               double* ws, const Ws& w, const CgFastLds& o, bool need_T,
-                              double* fast = nullptr, size_t fast_cap = 0, bool da_fast = false) {
+                              double* fast = nullptr, size_t fast_cap = 0, bool da_fast = false,
+                              double* stage = nullptr, unsigned mn = 0, unsigned mN = 0) {
         // fast: LDS scratch that is dead during the set-up (the Jet2 arena of the directional passes).  The two
         // Gauss-Jordan inversions (one barrier-separated step per column) and, when the caller does not need the
         // primal arena afterwards (da_fast), the primal + Jacobian evaluation run there instead of in the HBM workspace.
@@ -89,7 +99,12 @@ struct CgDerivs {
         const bool inv_lds = da_fast || (fast && fast_cap >= inv_scratch_doubles(n));
         double* da = da_fast ? fast : ws + w.da; double* x = ws + w.x;
         double* sc = inv_lds ? fast + (da_fast ? (size_t)o.total : 0) : nullptr;
-        for (int e = b.tid; e < N; e += b.nthr) x[e] = xg[e];
+        double* kocc = ws + w.kocc;             // wave vectors of the occupied orbitals, staged once (the loops below used to chase
+        for (int e = b.tid; e < N; e += b.nthr) {                   // state_idx -> orbital table through global memory per term)
+            x[e] = xg[e];
+            const int j = e / D;
+            kocc[e] = spk[(size_t)sidx[j] * D + (e - j * D)];
+        }
         b.sync();
         const typename F::WFrag* wf = nullptr;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -97,6 +112,7 @@ struct CgDerivs {
         if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
 #endif
         F::primal(b, th, (const double*)x, n, L, da, o, wf);
+        LP::pt_build(b, da + o.sh, da + o.ch, n, mn ? mn : cg_div_magic((unsigned)n), ws + w.pt);
         F::jacobian(b, th, n, L, da, o, wf);
         // with the arena in LDS its J slot (dead after the set-up) is inverted in place
         double* Jc = da_fast ? da + o.J : (inv_lds ? sc : ws + w.Jc);
@@ -109,7 +125,7 @@ struct CgDerivs {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (inv_lds && N <= 32 && n <= 16 && nn2 >= 128 && b.nthr >= 128) {
             // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (cg_linalg.hpp); scratch: Dc
-            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
             const int wave = b.tid >> 6;
             if (wave == 0) {
                 if (N == 26) cg_wave_inverse_real<26>(da + o.J, N, N, Jinv, N, Dc);
@@ -124,13 +140,30 @@ struct CgDerivs {
             inverted = true;
         }
 #endif
+        if (!inverted && stage) {
+            // larger systems: in-place Gauss-Jordan on an LDS copy of the matrix, the result scattered through the row permutation
+            if (!mN) { mn = cg_div_magic((unsigned)n); mN = cg_div_magic((unsigned)N); }
+            double* vec = stage + ((NN + 1) & ~(size_t)1); double* scs = vec + ((4 * N + 1) & ~1); int* rowsrc = (int*)(scs + 64);
+            for (int e = b.tid; e < N * N; e += b.nthr) stage[e] = da[o.J + e];
+            b.sync();
+            cg_inverse_inplace_real(b, stage, N, N, vec, scs, rowsrc, mN);
+            cg_inverse_scatter_real(b, stage, N, N, rowsrc, ws + w.Jinv, N, mN);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
+            for (int e = b.tid; e < 2 * n * n; e += b.nthr) stage[e] = da[o.Dm + e];
+            b.sync();
+            cg_inverse_inplace_complex(b, stage, n, n, vec, scs, rowsrc, mn);
+            Dinv = ws + w.Dinv;
+            cg_inverse_scatter_complex(b, stage, n, n, rowsrc, Dinv, n, mn);
+            b.sync();
+            inverted = true;
+        }
         if (!inverted) {
             if (!da_fast) {
                 for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
                 b.sync();
             }
             (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
-            F::slater_matrix(b, da + o.z, spk, sidx, n, da + o.Dm);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
             for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
             if (inv_lds) for (int e = b.tid; e < N * N; e += b.nthr) ws[w.Jinv + e] = Jinv[e];
             b.sync();
@@ -144,7 +177,7 @@ struct CgDerivs {
             const int i = e / D, a = e - i * D;
             double re = 0, im = 0;
             for (int j = 0; j < n; ++j) {
-                const double ka = spk[(size_t)sidx[j] * D + a];
+                const double ka = kocc[j * D + a];
                 const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
                 re += -ka * p.im; im += ka * p.re;           // (i k) * p
             }
@@ -155,7 +188,7 @@ struct CgDerivs {
                 const int a = e / (n * n), r = e - a * n * n, i = r / n, l = r - i * n;
                 double re = 0, im = 0;
                 for (int j = 0; j < n; ++j) {
-                    const double ka = spk[(size_t)sidx[j] * D + a];
+                    const double ka = kocc[j * D + a];
                     const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + l)], Dinv[2 * (j * n + l) + 1]});
                     re += -ka * p.im; im += ka * p.re;
                 }
@@ -165,7 +198,7 @@ struct CgDerivs {
                 const int a = e / (D * n), r = e - a * D * n, bb = r / n, i = r - bb * n;
                 double re = 0, im = 0;
                 for (int j = 0; j < n; ++j) {
-                    const double kk = -spk[(size_t)sidx[j] * D + a] * spk[(size_t)sidx[j] * D + bb];
+                    const double kk = -kocc[j * D + a] * kocc[j * D + bb];
                     const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
                     re += kk * p.re; im += kk * p.im;
                 }
@@ -189,7 +222,9 @@ struct CgDerivs {
     // One reverse sweep for cotangents (zbar, Jbar); adds the parameter gradient into gw[NP] (gw zeroed by caller).
     static CG_DEVI void reverse(const CgBlk& b, const double* __restrict__ th, int n, double L, double* ws, const Ws& w,
                                 const CgFastLds& o, const Adj& A, double* gw, const double* da,
-                                double* jslot = nullptr, double* hot = nullptr, size_t hot_cap = 0) {
+                                double* jslot = nullptr, double* hot = nullptr, size_t hot_cap = 0, bool jac = true) {
+        // jac = false: the Jacobian cotangent is zero (imaginary part: log|det J| is real) -- every adjoint that is linear in Jbar
+        // is zero-filled instead of computed (J6 ... J2: two of the three pair passes and all the N x 16 contractions)
         // jslot / hot: LDS that is dead during the sweep (the arena's J slot, the set-up's inversion scratch); the adjoint
         // arrays of the pair loops (Jhat; Gbar, Bbar, Vbar, U'bar while they fit) live there instead of in the HBM workspace.
         const int N = n * D;
@@ -200,7 +235,8 @@ struct CgDerivs {
             if (hot_left < cnt) return dflt;
             double* r = hot; hot += cnt; hot_left -= cnt; return r;
         };
-        const double *sh = da + o.sh, *ch = da + o.ch, *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
+        const double* PT = ws + w.pt;
+        const double *m0 = da + o.m0, *s1 = da + o.s1, *sg1 = da + o.sg1, *m1 = da + o.m1,
                      *gbar = da + o.gbar, *sg2 = da + o.sg2, *s2 = da + o.s2, *U = da + o.U, *V = da + o.V,
                      *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
         const double* zbar = ws + w.zbar; const double* Jbar = ws + w.Jbar;
@@ -213,25 +249,38 @@ struct CgDerivs {
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
 
+        if (!jac) {
+            for (int e = b.tid; e < N * P; e += b.nthr) Upb[e] = 0.0;
+            for (int e = b.tid; e < N * HS; e += b.nthr) { Bb[e] = 0.0; Ub[e] = 0.0; Rb[e] = 0.0; }
+            for (int e = b.tid; e < N * HT; e += b.nthr) Vb[e] = 0.0;
+            for (int e = b.tid; e < n * HS; e += b.nthr) sg1b[e] = 0.0;
+            for (int e = b.tid; e < n * HS * P; e += b.nthr) pW0[e] = 0.0;
+            for (int e = b.tid; e < n * HT * (P + 1); e += b.nthr) pWt[e] = 0.0;
+            b.sync();
+        } else {
         // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii  (k != i)
         for (int e = b.tid; e < N * N; e += b.nthr) {
             const int r = e / N, c = e - r * N, i = r / D, a = r - i * D, k = c / D, bb = c - k * D;
             Jhat[e] = (i == k) ? 0.0 : Jbar[e] - Jbar[(i * D + a) * N + i * D + bb];
         }
         b.sync();
-        // (J5) adjoints that are sums over k for fixed i
+        // (J5) adjoints that are sums over k for fixed i (pair features from the pair table; the k = i terms vanish with Jhat_ii = 0)
         for (int e = b.tid; e < N * P; e += b.nthr) {              // Upbar_i[a][f] = -sum_k sum_b Jhat_ik[a][b] T_ik[f][b]
             const int r = e / P, f = e - r * P, i = r / D;
+            const double* jr = Jhat + (size_t)r * N; const double* pr = PT + (size_t)i * n * PFS;
             double acc = 0;
-            for (int k = 0; k < n; ++k) {
-                if (k == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+            if (f < 2 * D) {
+                const int bb = f < D ? f : f - D, off = f < D ? D + bb : bb;
+                for (int k = 0; k < n; ++k) acc += jr[k * D + bb] * pr[k * PFS + off];
+                acc *= f < D ? c1 : -c1;
+            } else {
+                for (int k = 0; k < n; ++k) {
+                    double t = 0;
 #pragma unroll
-                for (int bb = 0; bb < D; ++bb) {
-                    const double tv = (f == bb) ? t.tc[bb] : (f == D + bb) ? t.ts[bb] : (f == 2 * D) ? t.td[bb] : 0.0;
-                    acc -= Jhat[r * N + k * D + bb] * tv;
+                    for (int bb = 0; bb < D; ++bb) t += jr[k * D + bb] * pr[k * PFS + D + bb];
+                    acc += t * pr[k * PFS + 2 * D + 1];
                 }
+                acc *= -c2c;
             }
             Upb[e] = acc;
         }
@@ -264,12 +313,11 @@ struct CgDerivs {
             for (int f = 0; f <= P; ++f) pw[f] = 0;
             for (int k = 0; k < n; ++k) {
                 if (k == i) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, i, k, pf);
-                TCol t; tcols(pf, c1, c2c, t);
-                double u = bt + wt[2 * D] * pf.del, q[D];
+                PairT t; LP::pt_load(PT, i * n + k, c1, c2c, t);
+                double u = bt + wt[2 * D] * t.del, q[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                    u += wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
                     q[a] = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
                 }
                 const double sg = sigmoid_only(u), sgp = sg * (1.0 - sg);
@@ -290,11 +338,11 @@ struct CgDerivs {
                 const double ub = sgb * sgp;          // adjoint of u_t (from sigma_t)
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    pw[a] += qb[a] * t.tc[a] + ub * pf.c2[a];
-                    pw[D + a] += qb[a] * t.ts[a] + ub * pf.s2[a];
+                    pw[a] += qb[a] * t.tc[a] + ub * t.c2[a];
+                    pw[D + a] += qb[a] * t.ts[a] + ub * t.s2[a];
                     pw[2 * D] += qb[a] * t.td[a];
                 }
-                pw[2 * D] += ub * pf.del;
+                pw[2 * D] += ub * t.del;
                 pw[P] += ub;
             }
 #pragma unroll
@@ -310,24 +358,25 @@ struct CgDerivs {
 #pragma unroll
             for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
             const double w_d = th[F::o_W0 + 2 * D * HS + h];
-            const double sgp = sg1[e];
+            const double sgp = sg1[e] * (rn * rn);
+            double gp[D];
+#pragma unroll
+            for (int bb = 0; bb < D; ++bb) gp[bb] = Gb[(p * HS + h) * D + bb];
             double sb = 0, pw[P];
 #pragma unroll
             for (int f = 0; f < P; ++f) pw[f] = 0;
             for (int q = 0; q < n; ++q) {
                 if (q == p) continue;
-                typename F::PairF pf; F::pairfeat(sh, ch, p, q, pf);
-                TCol t; tcols(pf, c1, c2c, t);
+                PairT t; LP::pt_load(PT, p * n + q, c1, c2c, t);
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) {
-                    const double dG = (Gb[(p * HS + h) * D + bb] - Gb[(q * HS + h) * D + bb]) * rn * rn;
-                    const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
-                    sb += dG * q0;
+                    const double dG = gp[bb] - Gb[(q * HS + h) * D + bb];
+                    sb += dG * (w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb]);
                     const double qb = dG * sgp;        // adjoint of q0_pq[h][bb]
                     pw[bb] += qb * t.tc[bb]; pw[D + bb] += qb * t.ts[bb]; pw[2 * D] += qb * t.td[bb];
                 }
             }
-            sg1b[e] = sb;
+            sg1b[e] = sb * (rn * rn);
 #pragma unroll
             for (int f = 0; f < P; ++f) pW0[(size_t)e * P + f] = pw[f];
         }
@@ -361,6 +410,7 @@ struct CgDerivs {
             Rb[e] = acc;
         }
         b.sync();
+        }   // jac
         // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  (F8) s2bar_i[h] = sum_a Wf[h][a] zbar_i[a]
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int i = e / HS, h = e - i * HS;
@@ -414,14 +464,14 @@ struct CgDerivs {
             for (int f = 0; f <= P; ++f) pw[f] = 0;
             const double mb = m1b[e] * rn;
             for (int j = 0; j < n; ++j) {
-                typename F::PairF pf; F::pairfeat(sh, ch, i, j, pf);
-                double u = bt + wt[2 * D] * pf.del;
+                const double* q = PT + (size_t)(i * n + j) * PFS;
+                double u = bt + wt[2 * D] * q[2 * D];
 #pragma unroll
-                for (int a = 0; a < D; ++a) u += wt[a] * pf.c2[a] + wt[D + a] * pf.s2[a];
+                for (int a = 0; a < D; ++a) u += wt[a] * q[a] + wt[D + a] * q[D + a];
                 const double ub = mb * sigmoid_only(u);
 #pragma unroll
-                for (int a = 0; a < D; ++a) { pw[a] += ub * pf.c2[a]; pw[D + a] += ub * pf.s2[a]; }
-                pw[2 * D] += ub * pf.del; pw[P] += ub;
+                for (int a = 0; a < D; ++a) { pw[a] += ub * q[a]; pw[D + a] += ub * q[D + a]; }
+                pw[2 * D] += ub * q[2 * D]; pw[P] += ub;
             }
 #pragma unroll
             for (int f = 0; f <= P; ++f) pWt[(size_t)e * (P + 1) + f] += pw[f];
@@ -494,7 +544,8 @@ struct CgDerivs {
         const Ws& w = lay.w;
         const CgFastLds& o = lay.o;
         double* fast = lay.vjp_fast ? lds + lds_doubles(n, b.nthr) : nullptr;
-        setup(b, th, xg, spk, sidx, n, L, ws, w, o, false, fast, (size_t)lay.vjp_fast, lay.vjp_da != 0);
+        double* stage = lay.stage ? lds + lds_doubles(n, b.nthr) : nullptr;
+        setup(b, th, xg, spk, sidx, n, L, ws, w, o, false, fast, (size_t)lay.vjp_fast, lay.vjp_da != 0, stage, lay.mn, lay.mN);
         const double* da = lay.vjp_da ? fast : ws + w.da;       // primal arena the reverse sweeps read
         const double* Jinv = ws + w.Jinv; const double* gz = ws + w.gz;
         double* zbar = ws + w.zbar; double* Jbar = ws + w.Jbar; double* gw = ws + w.gw;
@@ -502,12 +553,14 @@ struct CgDerivs {
         for (int pass = 0; pass < npass; ++pass) {
             const double wr = score ? (pass == 0 ? 1.0 : 0.0) : w_re;
             const double wi = score ? (pass == 0 ? 0.0 : 1.0) : w_im;
+            const bool jac = wr != 0.0;                          // the Jacobian cotangent w_re / 2 J^-T vanishes for the imaginary part
             for (int e = b.tid; e < N; e += b.nthr) zbar[e] = wr * gz[2 * e] + wi * gz[2 * e + 1];
-            for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
+            if (jac) for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
             for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
             b.sync();
-            reverse(b, th, n, L, ws, w, o, lay.a, gw, da, lay.vjp_da ? fast + o.J : nullptr,
-                    lay.vjp_da ? fast + o.total : nullptr, lay.vjp_da ? (size_t)lay.vjp_fast - o.total : 0);
+            // the LDS staging area of the inverses is dead by now: Jhat (the hottest array of the sweep) lives there when it exists
+            reverse(b, th, n, L, ws, w, o, lay.a, gw, da, lay.vjp_da ? fast + o.J : stage,
+                    lay.vjp_da ? fast + o.total : nullptr, lay.vjp_da ? (size_t)lay.vjp_fast - o.total : 0, jac);
             if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
             else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];
             b.sync();

@@ -9,10 +9,9 @@
 #define CG_UNIT_NAME(f) cg_derivs_a_##f
 #include "cg_k_derivs.inc"
 
-int cg_derivs_b_grad_lap(cg_ctx* c, int nt, int grid, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v,
+int cg_derivs_b_grad_lap(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v,
                          double* grad, double* lap);
-int cg_derivs_b_param_vjp(cg_ctx* c, int nt, int grid, const CgDev& m, const double* x, const int* sidx, int B, const double* w_re,
-                          const double* w_im, double* partial, double* score);
+int cg_derivs_b_param_vjp(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, double* score);
 int cg_derivs_b_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, double* score);
 
 // deterministic second-stage reduction of per-workgroup partial gradients: out[p] = sum_g partial[g][p]
@@ -178,9 +177,8 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     Arg al{lap, nullptr, sizeof(double) * (size_t)B * 2, false, true};
     Arg* all[] = {&ax, &as, &av, &ag, &al};
     for (Arg* a : all) if ((rc = stage(c, *a))) return rc;
-    const int nt = 256;
-    const int grid = std::min(B, c->cu_count * 2 * (c->fast ? 2 : CG_DERIV_WAVES));
     if (!c->fast) {
+        const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
         if ((rc = cg_gen_run_grad_lap(c, grid, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev,
                                       (double*)al.dev))) return rc;
         for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
@@ -188,9 +186,9 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     }
     const CgDev m = make_dev(c);
     bool launched = false;
-    if ((rc = cg_derivs_a_grad_lap(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev,
+    if ((rc = cg_derivs_a_grad_lap(c, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev, (double*)ag.dev,
                                    (double*)al.dev)) < 0) return rc;
-    if (rc == 0 && (rc = cg_derivs_b_grad_lap(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev,
+    if (rc == 0 && (rc = cg_derivs_b_grad_lap(c, m, (const double*)ax.dev, (const int*)as.dev, B, mode, (const double*)av.dev,
                                               (double*)ag.dev, (double*)al.dev)) < 0) return rc;
     launched = rc == 1;
     if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_grad_laplacian: configuration not instantiated");
@@ -243,45 +241,31 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
         }
         asc.dev = c->d_scores; c->scores_B = B;
     }
-    const int nt = 256;
-    const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
-    const CgDev m = make_dev(c);
-    bool launched = false;
     if (c->fast) {
-        // second-generation score kernel (cg_score.hpp) where the system fits its LDS plan: the scores go to the caller's buffer, the
-        // resident buffer or -- for a plain theta-VJP -- a temporary, and the weighted sum is the sliced GEMV over them
+        // depth-2 flow: per-sample scores first -- into the caller's buffer, the resident buffer or (plain theta-VJP) a temporary -- by
+        // the second-generation kernel (cg_score.hpp) where the system fits its LDS plan, otherwise by the first-generation one
+        // (cg_derivs.hpp); the weighted sum over the batch is then the sliced GEMV over the score matrix
+        const CgDev m = make_dev(c);
         double* sc = (double*)asc.dev;
-        if (!sc && g_theta) {
+        if (!sc) {
             sc = (double*)arena_take(c, asc.bytes);
             if (!sc) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
         }
-        if (sc) {
-            if ((rc = cg_derivs_a_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-            if (rc == 0 && (rc = cg_derivs_b_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-            if (rc == 1) {
-                launched = true;
-                if (g_theta && (rc = score_reduce(c, sc, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
-                g_theta = nullptr;                         // (done: skips the partial-row reduction of the first-generation kernel below)
-            }
-        }
-    }
-    double* partial = (g_theta && !launched) ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
-    if (g_theta && !launched && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
-    if (!c->fast) {       // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
+        if ((rc = cg_derivs_a_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+        if (rc == 0 && (rc = cg_derivs_b_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+        if (rc == 0 && (rc = cg_derivs_a_param_vjp(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+        if (rc == 0 && (rc = cg_derivs_b_param_vjp(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
+        if (rc != 1) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
+        if (g_theta && (rc = score_reduce(c, sc, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
+    } else {              // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
+        const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
+        double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;
+        if (g_theta && !partial) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
         if ((rc = cg_gen_run_param_vjp(c, grid, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev,
                                        partial, (double*)asc.dev))) return rc;
-        launched = true;
+        if (g_theta)
+            hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
     }
-    if (!launched) {
-        if ((rc = cg_derivs_a_param_vjp(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev, (const double*)awi.dev,
-                                        partial, (double*)asc.dev)) < 0) return rc;
-        if (rc == 0 && (rc = cg_derivs_b_param_vjp(c, nt, grid, m, (const double*)ax.dev, (const int*)as.dev, B, (const double*)awr.dev,
-                                                   (const double*)awi.dev, partial, (double*)asc.dev)) < 0) return rc;
-        launched = rc == 1;
-    }
-    if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
-    if (g_theta)
-        hipLaunchKernelGGL(k_reduce_rows, dim3((P + 127) / 128), dim3(128), 0, c->stream, (const double*)partial, grid, P, (double*)ag.dev);
     if (fisher) {
         if ((rc = fisher_complex_launch(c, (const double*)asc.dev, B, P, (double*)afi.dev))) return rc;
         if (smean && (rc = score_reduce(c, (const double*)asc.dev, nullptr, nullptr, B, 2 * P, (double*)asm_.dev))) return rc;

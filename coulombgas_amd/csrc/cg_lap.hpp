@@ -56,6 +56,7 @@ struct CgLap {
         int th_lds, th;     // 1: theta is copied to LDS at doubles offset th
         int P_lds, A_lds, B_lds;             // block placement
         unsigned P_off, A_off, B_off;        // block base (doubles) in its pool
+        int stage_lds; unsigned stage;       // N > 32: staging area of the in-place inverses (matrix + pivot row / column + bookkeeping)
         unsigned mn, mN;    // multiply-shift constants of e / n and e / (n D) (cg_div_magic)
         // P
         int red, x, gz, xbar, Jinv, Ta, Kd, TaKd_in_P;
@@ -160,6 +161,12 @@ struct CgLap {
         l.all_lds = (l.P_lds && l.A_lds && l.B_lds) ? 1 : 0;
         l.th_lds = 0; l.th = 0;
         if (theta_in_lds && lds + ev(NP) <= lds_budget_doubles) { l.th = (int)lds; lds += ev(NP); l.th_lds = 1; }
+        {   // the two inverses of the larger systems run in place on an LDS copy of the matrix when it fits (J: 104 KB at n = 57)
+            const bool wave_inv = N <= 32 && n <= 16 && nthr >= 128 && NN + nn2 >= 128;     // (set-up: register Gauss-Jordan, no staging)
+            const size_t st = wave_inv ? 0 : ev(NN) + ev(4 * N) + 64 + ev((N + 1) / 2);
+            if (lds + st <= lds_budget_doubles) { l.stage_lds = 1; l.stage = (unsigned)lds; lds += st; }
+            else { l.stage_lds = 0; l.stage = (unsigned)ws; ws += st; }
+        }
         l.lds_total = (unsigned)lds; l.ws_total = (unsigned)ws;
         return l;
     }
@@ -167,12 +174,13 @@ struct CgLap {
     // block base pointers of one workgroup
     template <bool AL>
     struct Mem {
-        double *p, *a, *b;
+        double *p, *a, *b, *st;
         CG_DEVI Mem(double* lds, double* ws, const Lay& l) {
             if (AL) { p = lds + l.P_off; a = lds + l.A_off; b = lds + l.B_off; }
             else {
                 p = (l.P_lds ? lds : ws) + l.P_off; a = (l.A_lds ? lds : ws) + l.A_off; b = (l.B_lds ? lds : ws) + l.B_off;
             }
+            st = (l.stage_lds ? lds : ws) + l.stage;
         }
     };
 
@@ -256,15 +264,18 @@ struct CgLap {
         }
 #endif
         if (!inverted) {
-            int* perm = (int*)(mem.a + l.perm);
-            for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
+            // in-place Gauss-Jordan on a staged copy (LDS when it fits), the result scattered back through the row permutation
+            double* st = mem.st; double* vec = st + ((N * N + 1) & ~1); double* sc = vec + ((4 * N + 1) & ~1); int* rowsrc = (int*)(sc + 64);
+            for (int e = b.tid; e < N * N; e += b.nthr) st[e] = da[o.J + e];
             b.sync();
-            (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+            cg_inverse_inplace_real(b, st, N, N, vec, sc, rowsrc, l.mN);
+            cg_inverse_scatter_real(b, st, N, N, rowsrc, Jinv, N, l.mN);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
-            for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
+            for (int e = b.tid; e < 2 * n * n; e += b.nthr) st[e] = da[o.Dm + e];
             b.sync();
-            double la, ar;
-            cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
+            cg_inverse_inplace_complex(b, st, n, n, vec, sc, rowsrc, l.mn);
+            cg_inverse_scatter_complex(b, st, n, n, rowsrc, Dinv, n, l.mn);
+            b.sync();
         }
         CG_STAMP_END(27)
         CG_STAMP_START(28)
@@ -362,6 +373,7 @@ struct CgLap {
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
         const unsigned mn = l.mn, mN = l.mN;
 
+        CG_STAMP_START(15)
         // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii (k != i),  Jbar = 1/2 J^-T;  Jhat_ii = 0
         for (int e = b.tid; e < N * N; e += b.nthr) {
             const int r = cg_udiv(e, mN), c = e - r * N, i = r / D, k = c / D, bb = c - k * D;
@@ -432,6 +444,7 @@ struct CgLap {
             for (int a = 0; a < D; ++a) Vb[(i * D + a) * HT + h] = vb[a];
         }
         b.sync();
+        CG_STAMP(15)
         // (J4) G adjoint -> sg1bar (first part);  (J3) Up_i = (1/n) (U_i diag sg1_i) W0^T -> Ubar, sg1bar (second part)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int p = e / HS, h = e - p * HS;
@@ -526,6 +539,7 @@ struct CgLap {
             m0b[e] = acc;
         }
         b.sync();
+        CG_STAMP(16)
         // pair pass: adjoints of the features t0_ik (value: t0bar) and of their r-derivatives T_ik (Tc, Ts, Td), then rbar_ik
         for (int e = b.tid; e < n * n; e += b.nthr) {
             const int i = cg_udiv(e, mn), k = e - i * n;
@@ -616,6 +630,7 @@ struct CgLap {
             xbar[e] = acc;
         }
         b.sync();
+        CG_STAMP_END(17)
     }
 
     // ------------------------------------------------------------------------------------------------------
@@ -946,8 +961,11 @@ struct CgLap {
         const double* gz = mem.p + l.gz; const double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; const double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd;
         for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir ? dir[e] : (e == basis ? 1.0 : 0.0), 0.0);
         b.sync();
+        CG_STAMP_START(29)
         F::primal(b, th, (const Jet2*)xj, n, L, ja, oj, nullptr, dir ? -1 : basis / D);
+        CG_STAMP(29)
         F::jacobian(b, th, n, L, ja, oj);
+        CG_STAMP(30)
         const Jet2* zj = ja + oj.z; const Jet2* Jj = ja + oj.J;
         double p_re = 0, p_im = 0, t2 = 0, t3 = 0;
         if (want_phi2) {
@@ -986,6 +1004,7 @@ struct CgLap {
             t3 += M[al * N + ga] * M[ga * N + al];
         }
         red[0] = p_re; red[1] = p_im; red[2] = t2; red[3] = t3;
+        CG_STAMP_END(31)
     }
 
     template <bool AL>

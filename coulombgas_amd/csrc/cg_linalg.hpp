@@ -238,6 +238,97 @@ CG_DEVI void cg_inverse_complex(const CgBlk& b, double* A, int N, int lda, doubl
     arg = atan2(pm.im, pm.re);
 }
 
+// In-place Gauss-Jordan inverse with partial pivoting, the matrix resident in LDS (the derivative kernels at N > 32).
+// A (N x N, row-major, lda) is overwritten by (P A)^-1; rowsrc[l] = original row now at position l, so that
+//     A^-1[i][rowsrc[l]] = A_out[i][l]            (apply with cg_inverse_scatter_* while copying the result out).
+// vec: 2 N doubles of scratch (pivot column, scaled pivot row); sc: >= 48 doubles (argmax scratch); rowsrc: N ints.
+// Per column: parallel pivot search (one candidate per thread + wave/LDS argmax), physical row swap, then ONE sweep over the whole
+// matrix with the pivot row and column staged apart -- 5 barriers per column, every operand in LDS.  (The [A | I] version above
+// scans the pivot column serially in every thread and runs out of the HBM workspace at large N: 4-5 ms per matrix at N = 114.)
+CG_DEVI void cg_inverse_inplace_real(const CgBlk& b, double* A, int N, int lda, double* vec, double* sc, int* rowsrc, unsigned mN /* cg_div_magic(N) */) {
+    double* col = vec; double* row = vec + N;
+    for (int i = b.tid; i < N; i += b.nthr) rowsrc[i] = i;
+    b.sync();
+    for (int k = 0; k < N; ++k) {
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = k + b.tid; i < N; i += b.nthr) {
+            const double v = fabs(A[i * lda + k]);
+            if (v > best) { best = v; bi = i; }
+        }
+#if !defined(__HIP_DEVICE_COMPILE__)
+        (void)sc;
+#endif
+        int p = cg_block_argmax(b, best, bi, sc);
+        if (p < k || p >= N) p = k;                 // all-NaN column: keep the diagonal (NaN propagates)
+        if (p != k) {
+            for (int j = b.tid; j < N; j += b.nthr) { const double t = A[k * lda + j]; A[k * lda + j] = A[p * lda + j]; A[p * lda + j] = t; }
+            if (b.tid == 0) { const int t = rowsrc[k]; rowsrc[k] = rowsrc[p]; rowsrc[p] = t; }
+        }
+        b.sync();
+        const double rinv = 1.0 / A[k * lda + k];
+        for (int j = b.tid; j < N; j += b.nthr) {   // stage the pivot column and the scaled pivot row
+            col[j] = A[j * lda + k];
+            row[j] = j == k ? rinv : A[k * lda + j] * rinv;
+        }
+        b.sync();
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int i = cg_udiv(e, mN), j = e - i * N;
+            double v;
+            if (i == k) v = row[j];
+            else if (j == k) v = -col[i] * rinv;
+            else v = A[i * lda + j] - col[i] * row[j];
+            A[i * lda + j] = v;
+        }
+        b.sync();
+    }
+}
+CG_DEVI void cg_inverse_scatter_real(const CgBlk& b, const double* A, int N, int lda, const int* rowsrc, double* Ainv, int ldi, unsigned mN) {
+    for (int e = b.tid; e < N * N; e += b.nthr) { const int i = cg_udiv(e, mN), l = e - i * N; Ainv[i * ldi + rowsrc[l]] = A[i * lda + l]; }
+}
+// complex version (interleaved re, im; lda, ldi in complex elements).  vec: 4 N doubles.
+CG_DEVI void cg_inverse_inplace_complex(const CgBlk& b, double* A, int N, int lda, double* vec, double* sc, int* rowsrc, unsigned mN) {
+    double* col = vec; double* row = vec + 2 * N;
+    for (int i = b.tid; i < N; i += b.nthr) rowsrc[i] = i;
+    b.sync();
+    for (int k = 0; k < N; ++k) {
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = k + b.tid; i < N; i += b.nthr) {
+            const double* a = A + 2 * (i * lda + k);
+            const double v = a[0] * a[0] + a[1] * a[1];
+            if (v > best) { best = v; bi = i; }
+        }
+        int p = cg_block_argmax(b, best, bi, sc);
+        if (p < k || p >= N) p = k;
+        if (p != k) {
+            for (int j = b.tid; j < 2 * N; j += b.nthr) { const double t = A[2 * k * lda + j]; A[2 * k * lda + j] = A[2 * p * lda + j]; A[2 * p * lda + j] = t; }
+            if (b.tid == 0) { const int t = rowsrc[k]; rowsrc[k] = rowsrc[p]; rowsrc[p] = t; }
+        }
+        b.sync();
+        const CgCplx rinv = cinv({A[2 * (k * lda + k)], A[2 * (k * lda + k) + 1]});
+        for (int j = b.tid; j < N; j += b.nthr) {
+            col[2 * j] = A[2 * (j * lda + k)]; col[2 * j + 1] = A[2 * (j * lda + k) + 1];
+            const CgCplx r = j == k ? rinv : cmul({A[2 * (k * lda + j)], A[2 * (k * lda + j) + 1]}, rinv);
+            row[2 * j] = r.re; row[2 * j + 1] = r.im;
+        }
+        b.sync();
+        for (int e = b.tid; e < N * N; e += b.nthr) {
+            const int i = cg_udiv(e, mN), j = e - i * N;
+            CgCplx v;
+            if (i == k) v = {row[2 * j], row[2 * j + 1]};
+            else if (j == k) { const CgCplx t = cmul({col[2 * i], col[2 * i + 1]}, rinv); v = {-t.re, -t.im}; }
+            else { const CgCplx t = cmul({col[2 * i], col[2 * i + 1]}, {row[2 * j], row[2 * j + 1]}); v = {A[2 * (i * lda + j)] - t.re, A[2 * (i * lda + j) + 1] - t.im}; }
+            A[2 * (i * lda + j)] = v.re; A[2 * (i * lda + j) + 1] = v.im;
+        }
+        b.sync();
+    }
+}
+CG_DEVI void cg_inverse_scatter_complex(const CgBlk& b, const double* A, int N, int lda, const int* rowsrc, double* Ainv, int ldi, unsigned mN) {
+    for (int e = b.tid; e < N * N; e += b.nthr) {
+        const int i = cg_udiv(e, mN), l = e - i * N;
+        Ainv[2 * (i * ldi + rowsrc[l])] = A[2 * (i * lda + l)]; Ainv[2 * (i * ldi + rowsrc[l]) + 1] = A[2 * (i * lda + l) + 1];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Wave-level helpers (gfx950 only) shared by the register / LDS LUs below.
 // ------------------------------------------------------------------------------------------------------------

@@ -11,7 +11,8 @@ from coulombgas_amd import _lib
 NAMES = {20: "set-up (primal, J, J^-1, D^-1, T, K)", 21: "Slater part (J^T g, tr J^T H J)", 22: "reverse sweep (xbar)",
          23: "forward Laplacian", 24: "jet pass(es)"}
 SUB = {25: "set-up: x, k_occ, primal", 26: "set-up: pair table + Jacobian assembly", 27: "set-up: Slater matrix + both inverses",
-       28: "set-up: T^a, diag K^ab, g"}
+       28: "set-up: T^a, diag K^ab, g", 15: "reverse: Jhat, U'bar, Bbar, Gbar, Vbar", 16: "reverse: dense chain (sg1bar ... m0bar)",
+       17: "reverse: pair pass + xbar", 29: "jet: primal", 30: "jet: Jacobian assembly", 31: "jet: traces"}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 mode = int(sys.argv[3]) if len(sys.argv) > 3 else 2
