@@ -149,6 +149,13 @@ struct CgLap {
             if (lds + sz <= lds_budget_doubles) { in_lds = 1; off = (unsigned)lds; lds += sz; }
             else { in_lds = 0; off = (unsigned)ws; ws += sz; }
         };
+        {   // N > 32: the two inverses run in place on an LDS copy of the matrix when it fits (J: 104 KB at n = 57); the reverse sweep
+            // then keeps Jhat there.  Placed FIRST: a resident staging area is worth more than the persistent block P.
+            const bool wave_inv = N <= 32 && n <= 16 && nthr >= 128 && NN + nn2 >= 128;     // (set-up: register Gauss-Jordan, no staging)
+            const size_t st = wave_inv ? 0 : ev(NN) + ev(4 * N) + 64 + ev((N + 1) / 2);
+            if (st + ev(NP) <= lds_budget_doubles) { l.stage_lds = 1; l.stage = (unsigned)lds; lds += st; }
+            else { l.stage_lds = 0; l.stage = (unsigned)ws; ws += st; }
+        }
         place(P_size, l.P_lds, l.P_off);
         if (lds + AB <= lds_budget_doubles) { l.A_lds = l.B_lds = 1; l.A_off = l.B_off = (unsigned)lds; lds += AB; }
         else if (A_size <= B_size) {          // the larger block goes to the workspace; the smaller may still fit
@@ -161,12 +168,6 @@ struct CgLap {
         l.all_lds = (l.P_lds && l.A_lds && l.B_lds) ? 1 : 0;
         l.th_lds = 0; l.th = 0;
         if (theta_in_lds && lds + ev(NP) <= lds_budget_doubles) { l.th = (int)lds; lds += ev(NP); l.th_lds = 1; }
-        {   // the two inverses of the larger systems run in place on an LDS copy of the matrix when it fits (J: 104 KB at n = 57)
-            const bool wave_inv = N <= 32 && n <= 16 && nthr >= 128 && NN + nn2 >= 128;     // (set-up: register Gauss-Jordan, no staging)
-            const size_t st = wave_inv ? 0 : ev(NN) + ev(4 * N) + 64 + ev((N + 1) / 2);
-            if (lds + st <= lds_budget_doubles) { l.stage_lds = 1; l.stage = (unsigned)lds; lds += st; }
-            else { l.stage_lds = 0; l.stage = (unsigned)ws; ws += st; }
-        }
         l.lds_total = (unsigned)lds; l.ws_total = (unsigned)ws;
         return l;
     }
@@ -366,7 +367,9 @@ struct CgLap {
         const double *sg1 = da + o.sg1, *sg2 = da + o.sg2, *U = da + o.U, *V = da + o.V, *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
         const double* PT = mem.a + l.pt;
         const double* Jinv = mem.p + l.Jinv;
-        double *Jhat = mem.a + l.Jhat, *Upb = mem.a + l.Upb, *Vb = mem.a + l.Vb, *Bb = mem.a + l.Bb, *Gb = mem.a + l.Gb, *sg1b = mem.a + l.sg1b,
+        // Jhat, read N times per entry by the sweep: in the LDS staging area of the inverses (dead after the set-up) when A is not in LDS
+        double *Jhat = (!AL && !l.A_lds && l.stage_lds) ? mem.st : mem.a + l.Jhat;
+        double *Upb = mem.a + l.Upb, *Vb = mem.a + l.Vb, *Bb = mem.a + l.Bb, *Gb = mem.a + l.Gb, *sg1b = mem.a + l.sg1b,
                *sg2b = mem.a + l.sg2b, *Ub = mem.a + l.Ub, *Rb = mem.a + l.Rb, *u2b = mem.a + l.u2b, *u1b = mem.a + l.u1b, *s1b = mem.a + l.s1b,
                *m1b = mem.a + l.m1b, *gbb = mem.a + l.gbb, *su2 = mem.a + l.su2, *m0b = mem.a + l.m0b, *rbar = mem.a + l.rbar, *xbar = mem.p + l.xbar;
         const double rn = 1.0 / (double)n;

@@ -11,6 +11,35 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# bench.py's N > 1 branch (torch.distributed rendezvous, RCCL communicator from the library, device-side accept-rate pmean) on a
+# one-GPU box: launched ONCE, at session start -- before this process has touched the GPU -- as a child under torch.distributed.run
+# with one rank and CG_FORCE_DIST=1; tests/test_gpu_rccl.py asserts on what it printed.
+BENCH_DIST = {}
+
+
+def pytest_sessionstart(session):
+    expr = session.config.getoption("-m") or ""
+    if "gpu" not in expr or "not gpu" in expr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:          # (counting devices does not initialise the GPU)
+            return
+    except ImportError:
+        return
+    import subprocess
+    env = dict(os.environ, CG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + os.getpid() % 200
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-energy-check", "--no-update-extras"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        BENCH_DIST.update(rc=r.returncode, out=r.stdout, err=r.stderr[-4000:])
+    except Exception as e:                          # noqa: BLE001 -- reported by the test
+        BENCH_DIST.update(rc=-1, out="", err=repr(e))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
