@@ -67,7 +67,7 @@ struct CgDerivs {
     struct Layout { Ws w; Adj a; CgFastLds o; int vjp_fast; int vjp_da; int stage; unsigned mn, mN; };
     static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
     static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
-    static CG_HD size_t stage_doubles(int n) { const size_t N = (size_t)n * D; return ((N * N + 1) & ~(size_t)1) + ((4 * N + 1) & ~(size_t)1) + 64 + ((N + 1) / 2 + 1 & ~(size_t)1); }
+    static CG_HD size_t stage_doubles(int n) { const size_t N = (size_t)n * D; return (5 * N + 64 + 1) & ~(size_t)1; }    // LDS scratch of cg_inverse_tile_*
     static Layout layout(int n, int nthr = 256, size_t lds_max_bytes = VJP_LDS_MAX_BYTES) {
         Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
         l.mn = cg_div_magic((unsigned)n); l.mN = cg_div_magic((unsigned)(n * D));
@@ -140,23 +140,32 @@ struct CgDerivs {
             inverted = true;
         }
 #endif
-        if (!inverted && stage) {
-            // larger systems: in-place Gauss-Jordan on an LDS copy of the matrix, the result scattered through the row permutation
-            if (!mN) { mn = cg_div_magic((unsigned)n); mN = cg_div_magic((unsigned)N); }
-            double* vec = stage + ((NN + 1) & ~(size_t)1); double* scs = vec + ((4 * N + 1) & ~1); int* rowsrc = (int*)(scs + 64);
-            for (int e = b.tid; e < N * N; e += b.nthr) stage[e] = da[o.J + e];
-            b.sync();
-            cg_inverse_inplace_real(b, stage, N, N, vec, scs, rowsrc, mN);
-            cg_inverse_scatter_real(b, stage, N, N, rowsrc, ws + w.Jinv, N, mN);
+#if defined(__HIP_DEVICE_COMPILE__)
+        double* stg = stage ? stage : sc;       // LDS scratch of the tiled inverses: the staging area, or the old inversion scratch
+        if (!inverted && stg && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
+            // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
+            cg_inverse_tile_real<8, 4>(b, da + o.J, N, N, ws + w.Jinv, N, stg);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
-            for (int e = b.tid; e < 2 * n * n; e += b.nthr) stage[e] = da[o.Dm + e];
-            b.sync();
-            cg_inverse_inplace_complex(b, stage, n, n, vec, scs, rowsrc, mn);
             Dinv = ws + w.Dinv;
-            cg_inverse_scatter_complex(b, stage, n, n, rowsrc, Dinv, n, mn);
-            b.sync();
+            cg_inverse_tile_complex<4, 4>(b, da + o.Dm, n, n, Dinv, n, stg);
             inverted = true;
         }
+#elif !defined(__HIPCC__)
+        if (!inverted) {     // host shim: in-place Gauss-Jordan on a copy
+            if (!mN) { mn = cg_div_magic((unsigned)n); mN = cg_div_magic((unsigned)N); }
+            std::vector<double> st((size_t)N * N + 4 * N + 64 + N);
+            double* vec = st.data() + (size_t)N * N; double* scs = vec + 4 * N; int* rowsrc = (int*)(scs + 64);
+            for (int e = 0; e < N * N; ++e) st[e] = da[o.J + e];
+            cg_inverse_inplace_real(b, st.data(), N, N, vec, scs, rowsrc, mN);
+            cg_inverse_scatter_real(b, st.data(), N, N, rowsrc, ws + w.Jinv, N, mN);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
+            for (int e = 0; e < 2 * n * n; ++e) st[e] = da[o.Dm + e];
+            cg_inverse_inplace_complex(b, st.data(), n, n, vec, scs, rowsrc, mn);
+            Dinv = ws + w.Dinv;
+            cg_inverse_scatter_complex(b, st.data(), n, n, rowsrc, Dinv, n, mn);
+            inverted = true;
+        }
+#endif
         if (!inverted) {
             if (!da_fast) {
                 for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
@@ -284,22 +293,11 @@ struct CgDerivs {
             }
             Upb[e] = acc;
         }
-        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]
-            const int r = e / HS, g = e - r * HS;
-            double acc = 0;
-            for (int k = 0; k < n; ++k)
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[F::iG(k, g, bb)];
-            Bb[e] = acc;
-        }
-        for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
-            const int k = e / (HS * D), r = e - k * HS * D, g = r / D, bb = r - g * D;
-            double acc = 0;
-            for (int i = 0; i < n; ++i)
-#pragma unroll
-                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[F::iB(i, a, g)];
-            Gb[e] = acc;
-        }
+        // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]  and  Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]: (N x N)(N x 16) on MFMA
+        cg_gemm_wg(b, N, HS, N, [&](int r, int c) { return Jhat[r * N + c]; }, [&](int c, int g) { return G[F::iG(c / D, g, c % D)]; },
+                   [&](int r, int g, double v) { Bb[r * HS + g] = v; });
+        cg_gemm_wg(b, N, HS, N, [&](int c, int r) { return Jhat[r * N + c]; }, [&](int r, int g) { return Bm[F::iB(r / D, r % D, g)]; },
+                   [&](int c, int g, double v) { Gb[((c / D) * HS + g) * D + (c % D)] = v; });
         // (J5) pair pass in (i,h) layout: Vbar_i[:,h], and the sigma_t / q_t adjoints -> partial Wtbar / btbar
         for (int e = b.tid; e < n * HT; e += b.nthr) {
             const int i = e / HT, h = e - i * HT;
@@ -400,15 +398,9 @@ struct CgDerivs {
         }
         b.sync();
         // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]
-        for (int e = b.tid; e < N * HS; e += b.nthr) {
-            const int r = e / HS, h = e - r * HS;
-            double acc = 0;
-#pragma unroll
-            for (int g = 0; g < HS; ++g) acc += Ub[r * HS + g] * th[F::o_Wa + g * HS + h] + Bb[r * HS + g] * th[F::o_Wb + g * HS + h];
-#pragma unroll
-            for (int g = 0; g < HT; ++g) acc += rn * Vb[r * HT + g] * th[F::o_Wc + g * HS + h];
-            Rb[e] = acc;
-        }
+        cg_gemm_wg(b, N, HS, 2 * HS + HT,       // one (N x (2 HS + HT))((2 HS + HT) x HS) product: the rows of Wa, Wb, Wc are consecutive in theta
+                   [&](int r, int k) { return k < HS ? Ub[r * HS + k] : k < 2 * HS ? Bb[r * HS + k - HS] : rn * Vb[r * HT + k - 2 * HS]; },
+                   [&](int k, int h) { return th[F::o_Wa + k * HS + h]; }, [&](int r, int h, double v) { Rb[r * HS + h] = v; });
         b.sync();
         }   // jac
         // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  (F8) s2bar_i[h] = sum_a Wf[h][a] zbar_i[a]
@@ -558,8 +550,7 @@ struct CgDerivs {
             if (jac) for (int e = b.tid; e < N * N; e += b.nthr) { const int al = e / N, be = e - al * N; Jbar[e] = 0.5 * wr * Jinv[be * N + al]; }
             for (int e = b.tid; e < NP; e += b.nthr) gw[e] = 0.0;
             b.sync();
-            // the LDS staging area of the inverses is dead by now: Jhat (the hottest array of the sweep) lives there when it exists
-            reverse(b, th, n, L, ws, w, o, lay.a, gw, da, lay.vjp_da ? fast + o.J : stage,
+            reverse(b, th, n, L, ws, w, o, lay.a, gw, da, lay.vjp_da ? fast + o.J : nullptr,
                     lay.vjp_da ? fast + o.total : nullptr, lay.vjp_da ? (size_t)lay.vjp_fast - o.total : 0, jac);
             if (score) for (int e = b.tid; e < NP; e += b.nthr) score[2 * e + pass] = gw[e];
             else if (gacc) for (int e = b.tid; e < NP; e += b.nthr) gacc[e] += gw[e];

@@ -149,10 +149,9 @@ struct CgLap {
             if (lds + sz <= lds_budget_doubles) { in_lds = 1; off = (unsigned)lds; lds += sz; }
             else { in_lds = 0; off = (unsigned)ws; ws += sz; }
         };
-        {   // N > 32: the two inverses run in place on an LDS copy of the matrix when it fits (J: 104 KB at n = 57); the reverse sweep
-            // then keeps Jhat there.  Placed FIRST: a resident staging area is worth more than the persistent block P.
+        {   // N > 32: LDS scratch of the register-tiled Gauss-Jordan inverses (cg_inverse_tile_*)
             const bool wave_inv = N <= 32 && n <= 16 && nthr >= 128 && NN + nn2 >= 128;     // (set-up: register Gauss-Jordan, no staging)
-            const size_t st = wave_inv ? 0 : ev(NN) + ev(4 * N) + 64 + ev((N + 1) / 2);
+            const size_t st = wave_inv ? 0 : ev(5 * N + 64);             // pivot row / column (double-buffered), candidates, pivots
             if (st + ev(NP) <= lds_budget_doubles) { l.stage_lds = 1; l.stage = (unsigned)lds; lds += st; }
             else { l.stage_lds = 0; l.stage = (unsigned)ws; ws += st; }
         }
@@ -264,36 +263,62 @@ struct CgLap {
             inverted = true;
         }
 #endif
-        if (!inverted) {
-            // in-place Gauss-Jordan on a staged copy (LDS when it fits), the result scattered back through the row permutation
-            double* st = mem.st; double* vec = st + ((N * N + 1) & ~1); double* sc = vec + ((4 * N + 1) & ~1); int* rowsrc = (int*)(sc + 64);
-            for (int e = b.tid; e < N * N; e += b.nthr) st[e] = da[o.J + e];
-            b.sync();
-            cg_inverse_inplace_real(b, st, N, N, vec, sc, rowsrc, l.mN);
-            cg_inverse_scatter_real(b, st, N, N, rowsrc, Jinv, N, l.mN);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (!inverted && l.stage_lds && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
+            // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
+            cg_inverse_tile_real<8, 4>(b, da + o.J, N, N, Jinv, N, mem.st);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
-            for (int e = b.tid; e < 2 * n * n; e += b.nthr) st[e] = da[o.Dm + e];
+            cg_inverse_tile_complex<4, 4>(b, da + o.Dm, n, n, Dinv, n, mem.st);
+            inverted = true;
+        }
+#elif !defined(__HIPCC__)
+        if (!inverted) {     // host shim: in-place Gauss-Jordan on a copy, the result scattered back through the row permutation
+            std::vector<double> st((size_t)N * N + 4 * N + 64 + N);
+            double* vec = st.data() + (size_t)N * N; double* sc = vec + 4 * N; int* rowsrc = (int*)(sc + 64);
+            for (int e = 0; e < N * N; ++e) st[e] = da[o.J + e];
+            cg_inverse_inplace_real(b, st.data(), N, N, vec, sc, rowsrc, l.mN);
+            cg_inverse_scatter_real(b, st.data(), N, N, rowsrc, Jinv, N, l.mN);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
+            for (int e = 0; e < 2 * n * n; ++e) st[e] = da[o.Dm + e];
+            cg_inverse_inplace_complex(b, st.data(), n, n, vec, sc, rowsrc, l.mn);
+            cg_inverse_scatter_complex(b, st.data(), n, n, rowsrc, Dinv, n, l.mn);
+            inverted = true;
+        }
+#endif
+        if (!inverted) {     // (beyond the tiled version's reach: [A | I] Gauss-Jordan in the workspace)
+            int* perm = (int*)(mem.a + l.perm);
+            for (int e = b.tid; e < N * N; e += b.nthr) Jc[e] = da[o.J + e];
             b.sync();
-            cg_inverse_inplace_complex(b, st, n, n, vec, sc, rowsrc, l.mn);
-            cg_inverse_scatter_complex(b, st, n, n, rowsrc, Dinv, n, l.mn);
+            (void)cg_inverse_real(b, Jc, N, N, Jinv, N, perm);
+            F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
+            for (int e = b.tid; e < 2 * n * n; e += b.nthr) Dc[e] = da[o.Dm + e];
             b.sync();
+            double la, ar;
+            cg_inverse_complex(b, Dc, n, n, Dinv, n, perm, la, ar);
         }
         CG_STAMP_END(27)
         CG_STAMP_START(28)
         const double* Dm = da + o.Dm;
         double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd; double* gz = mem.p + l.gz;
         const int nn = n * n;
-        for (int e = b.tid; e < D * nn; e += b.nthr) {               // T^a = D diag(i k^a) D^-1
-            const int a = e >= nn ? (D > 2 && e >= 2 * nn ? 2 : 1) : 0, r = e - a * nn, i = cg_udiv(r, l.mn), q = r - i * n;
-            double re = 0, im = 0;
-            for (int j = 0; j < n; ++j) {
-                const double ka = kocc[j * D + a];
-                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + q)], Dinv[2 * (j * n + q) + 1]});
-                re += -ka * p.im; im += ka * p.re;
-            }
-            Ta[2 * e] = re; Ta[2 * e + 1] = im;
-            if (i == q) { gz[2 * (i * D + a)] = re; gz[2 * (i * D + a) + 1] = im; }   // g_ia = T^a_ii
-        }
+        // T^a = D diag(i k^a) D^-1 for all directions as ONE real product on the matrix cores: with X^a = D diag(i k^a) and Y = D^-1,
+        //   [Re T^a | Im T^a] = [X^a_re | X^a_im] [[Y_re, Y_im], [-Y_im, Y_re]]      rows (a, i), columns (part, q), K = 2 n;   g_ia = T^a_ii
+        (void)nn;
+        cg_gemm_wg(b, D * n, 2 * n, 2 * n,
+                   [&](int r, int kk) {
+                       const int a = r >= n ? (D > 2 && r >= 2 * n ? 2 : 1) : 0, i = r - a * n, j = kk < n ? kk : kk - n;
+                       return kk < n ? -kocc[j * D + a] * Dm[2 * (i * n + j) + 1] : kocc[j * D + a] * Dm[2 * (i * n + j)];
+                   },
+                   [&](int kk, int c) {
+                       const int part = c >= n ? 1 : 0, q = c - part * n, j = kk < n ? kk : kk - n;
+                       const double yr = Dinv[2 * (j * n + q)], yi = Dinv[2 * (j * n + q) + 1];
+                       return kk < n ? (part ? yi : yr) : (part ? yr : -yi);
+                   },
+                   [&](int r, int c, double v) {
+                       const int a = r >= n ? (D > 2 && r >= 2 * n ? 2 : 1) : 0, i = r - a * n, part = c >= n ? 1 : 0, q = c - part * n;
+                       Ta[2 * ((a * n + i) * n + q) + part] = v;
+                       if (i == q) gz[2 * (i * D + a) + part] = v;
+                   });
         for (int e = b.tid; e < D * D * n; e += b.nthr) {            // diag of K^ab = D diag(-k^a k^b) D^-1
             const int i = e / (D * D), r = e - i * D * D, a = r / D, bb = r - a * D;
             double re = 0, im = 0;
@@ -327,13 +352,8 @@ struct CgLap {
         }
         p_re = 0; p_im = 0;
         if (!want_lap) return;
-        for (int e = b.tid; e < N * N; e += b.nthr) {
-            const int al = e / N, be = e - al * N;
-            if (be < al) continue;
-            double c = 0;
-            for (int k = 0; k < N; ++k) c += J[al * N + k] * J[be * N + k];
-            C[al * N + be] = c; C[be * N + al] = c;
-        }
+        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
+                   [&](int r, int c, double v) { C[r * N + c] = v; });          // C = J J^T (matrix cores)
         b.sync();
         for (int e = b.tid; e < n * D * D; e += b.nthr) {
             const int i = e / (D * D), r = e - i * D * D, a = r / D, bb = r - a * D;
@@ -367,8 +387,7 @@ struct CgLap {
         const double *sg1 = da + o.sg1, *sg2 = da + o.sg2, *U = da + o.U, *V = da + o.V, *Bm = da + o.Bm, *Up = da + o.Up, *G = da + o.G;
         const double* PT = mem.a + l.pt;
         const double* Jinv = mem.p + l.Jinv;
-        // Jhat, read N times per entry by the sweep: in the LDS staging area of the inverses (dead after the set-up) when A is not in LDS
-        double *Jhat = (!AL && !l.A_lds && l.stage_lds) ? mem.st : mem.a + l.Jhat;
+        double *Jhat = mem.a + l.Jhat;
         double *Upb = mem.a + l.Upb, *Vb = mem.a + l.Vb, *Bb = mem.a + l.Bb, *Gb = mem.a + l.Gb, *sg1b = mem.a + l.sg1b,
                *sg2b = mem.a + l.sg2b, *Ub = mem.a + l.Ub, *Rb = mem.a + l.Rb, *u2b = mem.a + l.u2b, *u1b = mem.a + l.u1b, *s1b = mem.a + l.s1b,
                *m1b = mem.a + l.m1b, *gbb = mem.a + l.gbb, *su2 = mem.a + l.su2, *m0b = mem.a + l.m0b, *rbar = mem.a + l.rbar, *xbar = mem.p + l.xbar;
@@ -403,22 +422,11 @@ struct CgLap {
             }
             Upb[e] = acc;
         }
-        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]
-            const int r = e / HS, g = e - r * HS;
-            double acc = 0;
-            for (int k = 0; k < n; ++k)
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[F::iG(k, g, bb)];
-            Bb[e] = acc;
-        }
-        for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
-            const int k = e / (HS * D), r = e - k * HS * D, g = r / D, bb = r - g * D;
-            double acc = 0;
-            for (int i = 0; i < n; ++i)
-#pragma unroll
-                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[F::iB(i, a, g)];
-            Gb[e] = acc;
-        }
+        // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]  and  Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]: (N x N)(N x 16) on MFMA
+        cg_gemm_wg(b, N, HS, N, [&](int r, int c) { return Jhat[r * N + c]; }, [&](int c, int g) { return G[F::iG(c / D, g, c % D)]; },
+                   [&](int r, int g, double v) { Bb[r * HS + g] = v; });
+        cg_gemm_wg(b, N, HS, N, [&](int c, int r) { return Jhat[r * N + c]; }, [&](int r, int g) { return Bm[F::iB(r / D, r % D, g)]; },
+                   [&](int c, int g, double v) { Gb[((c / D) * HS + g) * D + (c % D)] = v; });
         for (int e = b.tid; e < n * HT; e += b.nthr) {             // Vbar_i[a][h] = -sum_k sum_b Jhat_ik[a][b] sig_t(u_ik[h]) q_ik[h][b]
             const int i = e / HT, h = e - i * HT;
             double wt[P]; const double bt = th[F::o_t0b + h];
@@ -482,16 +490,11 @@ struct CgLap {
             Ub[e] = acc * rn * sg1[i * HS + g];
         }
         b.sync();
-        // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]
-        for (int e = b.tid; e < N * HS; e += b.nthr) {
-            const int r = e / HS, h = e - r * HS;
-            double acc = 0;
-#pragma unroll
-            for (int g = 0; g < HS; ++g) acc += Ub[r * HS + g] * th[F::o_Wa + g * HS + h] + Bb[r * HS + g] * th[F::o_Wb + g * HS + h];
-#pragma unroll
-            for (int g = 0; g < HT; ++g) acc += rn * Vb[r * HT + g] * th[F::o_Wc + g * HS + h];
-            Rb[e] = acc;
-        }
+        // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]: one (N x (2 HS + HT))((2 HS + HT) x HS) product
+        // (the rows of Wa, Wb, Wc are consecutive in theta)
+        cg_gemm_wg(b, N, HS, 2 * HS + HT,
+                   [&](int r, int k) { return k < HS ? Ub[r * HS + k] : k < 2 * HS ? Bb[r * HS + k - HS] : rn * Vb[r * HT + k - 2 * HS]; },
+                   [&](int k, int h) { return th[F::o_Wa + k * HS + h]; }, [&](int r, int h, double v) { Rb[r * HS + h] = v; });
         b.sync();
         // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  u2bar = sg2bar sg2'   (zbar = 0: no s2bar)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
@@ -995,15 +998,14 @@ struct CgLap {
             }
         }
         for (int e = b.tid; e < N * N; e += b.nthr) {
-            const int al = e / N, ga = e - al * N;
+            const int al = cg_udiv(e, l.mN), ga = e - al * N;
             t2 += Jinv[al * N + ga] * Jj[ga * N + al].dd;
-            double m = 0;
-            for (int k = 0; k < N; ++k) m += Jinv[al * N + k] * Jj[k * N + ga].d;
-            M[e] = m;
         }
+        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return Jinv[r * N + k]; }, [&](int k, int c) { return Jj[k * N + c].d; },
+                   [&](int r, int c, double v) { M[r * N + c] = v; });          // M = J^-1 J' (matrix cores)
         b.sync();
         for (int e = b.tid; e < N * N; e += b.nthr) {
-            const int al = e / N, ga = e - al * N;
+            const int al = cg_udiv(e, l.mN), ga = e - al * N;
             t3 += M[al * N + ga] * M[ga * N + al];
         }
         red[0] = p_re; red[1] = p_im; red[2] = t2; red[3] = t3;

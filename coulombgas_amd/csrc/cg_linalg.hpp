@@ -353,6 +353,260 @@ __device__ __forceinline__ unsigned cg_wave_max_u32(unsigned v) {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
+// Register-tiled Gauss-Jordan inverse (gfx950; the derivative kernels at 32 < N <= 128).  Every thread keeps a TR x TC tile of
+// the matrix in registers for the whole elimination; rows never move (the pivot of column k is the unused row p_k of largest
+// modulus), so a step is: the owners of column k post their best candidate, everybody picks the winner, the owners of row p_k and
+// of column k publish them (double-buffered in LDS), everybody updates its tile -- two barriers and ~2 TR TC operations per thread
+// and step, no matrix traffic at all (the in-place LDS version above moves the whole matrix through LDS every column: 1.1 ms per
+// walker at N = 114).  In-place bookkeeping: slot k of the tile matrix ends as column p_k of the inverse of the row-permuted system:
+//     A^-1[k][p_j] = S[p_k][j]        (scattered straight to the destination).
+// A, Ainv: any memory; sc: LDS, >= 4 N + 32 + N doubles (complex: 8 N + 32 + N).  Needs ceil(N/TR) ceil(N/TC) <= nthr, ceil(N/TR) <= 16.
+// ------------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int TR, int TC>
+__device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+    const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
+    const int tr = b.tid / tcn, tc = b.tid - tr * tcn;
+    const bool act = b.tid < trn * tcn;
+    const int i0 = tr * TR, j0 = tc * TC;
+    double* rowb = sc; double* colb = sc + 2 * N; double* cv = sc + 4 * N; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    double a[TR][TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (act && i0 + ii < N && j0 + jj < N) ? A[(size_t)(i0 + ii) * lda + j0 + jj] : 0.0;
+    unsigned used = 0;
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;          // rows beyond the matrix never pivot
+    for (int k = 0; k < N; ++k) {
+        const int buf = k & 1;
+        const bool mycol = act && k >= j0 && k < j0 + TC;
+        if (mycol) {                                  // best unused row of column k in this tile
+            const int jk = k - j0;
+            double best = -2.0; int bi = 0x7fffffff;
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii) {
+                double v = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj) v = jj == jk ? a[ii][jj] : v;
+                v = fabs(v);
+                const bool free_row = !((used >> ii) & 1u);
+                if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }     // (an all-NaN column still gets a pivot row)
+                if (free_row && v > best) { best = v; bi = i0 + ii; }
+            }
+            cv[tr] = best; ci[tr] = bi;
+        }
+        b.sync();
+        double best = cv[0]; int p = ci[0];
+#pragma unroll 4
+        for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+        const bool myrow = act && p >= i0 && p < i0 + TR;
+        if (myrow) {
+            const int ip = p - i0;
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) {
+                double v = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < TR; ++ii) v = ii == ip ? a[ii][jj] : v;
+                if (j0 + jj < N) rowb[buf * N + j0 + jj] = v;
+            }
+            used |= 1u << ip;
+        }
+        if (mycol) {
+            const int jk = k - j0;
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii) {
+                double v = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj) v = jj == jk ? a[ii][jj] : v;
+                if (i0 + ii < N) colb[buf * N + i0 + ii] = v;
+            }
+        }
+        if (b.tid == 0) piv[k] = p;
+        if (myrow && mycol) {                         // the owner of the pivot publishes its reciprocal (one division per column, not one per thread)
+            double pv = 0.0;
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj) pv = (ii == p - i0 && jj == k - j0) ? a[ii][jj] : pv;
+            cv[16 + buf] = 1.0 / pv;
+        }
+        b.sync();
+        const double rinv = cv[16 + buf];
+        double rj[TC];
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj) rj[jj] = (j0 + jj < N ? rowb[buf * N + j0 + jj] : 0.0) * rinv;
+#pragma unroll
+        for (int ii = 0; ii < TR; ++ii) {
+            const double cI = i0 + ii < N ? colb[buf * N + i0 + ii] : 0.0;
+            const bool isp = i0 + ii == p;
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) {
+                const bool isk = j0 + jj == k;
+                const double upd = fma(-cI, rj[jj], a[ii][jj]);
+                a[ii][jj] = isp ? (isk ? rinv : rj[jj]) : (isk ? -cI * rinv : upd);
+            }
+        }
+    }
+    b.sync();
+    for (int t = b.tid; t < N; t += b.nthr) kinv[piv[t]] = t;
+    b.sync();
+    if (act) {
+#pragma unroll
+        for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj)
+                if (i0 + ii < N && j0 + jj < N) Ainv[(size_t)kinv[i0 + ii] * ldi + piv[j0 + jj]] = a[ii][jj];
+    }
+    b.sync();
+}
+// complex version: interleaved (re, im), lda / ldi in complex elements
+template <int TR, int TC>
+__device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+    const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
+    const int tr = b.tid / tcn, tc = b.tid - tr * tcn;
+    const bool act = b.tid < trn * tcn;
+    const int i0 = tr * TR, j0 = tc * TC;
+    double* rowb = sc; double* colb = sc + 4 * N; double* cv = sc + 8 * N; int* ci = (int*)(cv + 16); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    double ar[TR][TC], ai[TR][TC];
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj) {
+            const bool ok = act && i0 + ii < N && j0 + jj < N;
+            ar[ii][jj] = ok ? A[2 * ((size_t)(i0 + ii) * lda + j0 + jj)] : 0.0;
+            ai[ii][jj] = ok ? A[2 * ((size_t)(i0 + ii) * lda + j0 + jj) + 1] : 0.0;
+        }
+    unsigned used = 0;
+#pragma unroll
+    for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;
+    for (int k = 0; k < N; ++k) {
+        const int buf = k & 1;
+        const bool mycol = act && k >= j0 && k < j0 + TC;
+        if (mycol) {
+            const int jk = k - j0;
+            double best = -2.0; int bi = 0x7fffffff;
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii) {
+                double vr = 0.0, vi = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj) { vr = jj == jk ? ar[ii][jj] : vr; vi = jj == jk ? ai[ii][jj] : vi; }
+                const double v = vr * vr + vi * vi;
+                const bool free_row = !((used >> ii) & 1u);
+                if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }
+                if (free_row && v > best) { best = v; bi = i0 + ii; }
+            }
+            cv[tr] = best; ci[tr] = bi;
+        }
+        b.sync();
+        double best = cv[0]; int p = ci[0];
+#pragma unroll 4
+        for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+        const bool myrow = act && p >= i0 && p < i0 + TR;
+        if (myrow) {
+            const int ip = p - i0;
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) {
+                double vr = 0.0, vi = 0.0;
+#pragma unroll
+                for (int ii = 0; ii < TR; ++ii) { vr = ii == ip ? ar[ii][jj] : vr; vi = ii == ip ? ai[ii][jj] : vi; }
+                if (j0 + jj < N) { rowb[2 * (buf * N + j0 + jj)] = vr; rowb[2 * (buf * N + j0 + jj) + 1] = vi; }
+            }
+            used |= 1u << ip;
+        }
+        if (mycol) {
+            const int jk = k - j0;
+#pragma unroll
+            for (int ii = 0; ii < TR; ++ii) {
+                double vr = 0.0, vi = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < TC; ++jj) { vr = jj == jk ? ar[ii][jj] : vr; vi = jj == jk ? ai[ii][jj] : vi; }
+                if (i0 + ii < N) { colb[2 * (buf * N + i0 + ii)] = vr; colb[2 * (buf * N + i0 + ii) + 1] = vi; }
+            }
+        }
+        if (b.tid == 0) piv[k] = p;
+        b.sync();
+        const CgCplx rinv = cinv({colb[2 * (buf * N + p)], colb[2 * (buf * N + p) + 1]});
+        CgCplx rj[TC];
+#pragma unroll
+        for (int jj = 0; jj < TC; ++jj)
+            rj[jj] = j0 + jj < N ? cmul({rowb[2 * (buf * N + j0 + jj)], rowb[2 * (buf * N + j0 + jj) + 1]}, rinv) : CgCplx{0.0, 0.0};
+#pragma unroll
+        for (int ii = 0; ii < TR; ++ii) {
+            const CgCplx cI = i0 + ii < N ? CgCplx{colb[2 * (buf * N + i0 + ii)], colb[2 * (buf * N + i0 + ii) + 1]} : CgCplx{0.0, 0.0};
+            const bool isp = i0 + ii == p;
+            const CgCplx ck = cmul(cI, rinv);
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj) {
+                const bool isk = j0 + jj == k;
+                const CgCplx t = cmul(cI, rj[jj]);
+                const double ur = ar[ii][jj] - t.re, ui = ai[ii][jj] - t.im;
+                ar[ii][jj] = isp ? (isk ? rinv.re : rj[jj].re) : (isk ? -ck.re : ur);
+                ai[ii][jj] = isp ? (isk ? rinv.im : rj[jj].im) : (isk ? -ck.im : ui);
+            }
+        }
+    }
+    b.sync();
+    for (int t = b.tid; t < N; t += b.nthr) kinv[piv[t]] = t;
+    b.sync();
+    if (act) {
+#pragma unroll
+        for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < TC; ++jj)
+                if (i0 + ii < N && j0 + jj < N) {
+                    double* o = Ainv + 2 * ((size_t)kinv[i0 + ii] * ldi + piv[j0 + jj]);
+                    o[0] = ar[ii][jj]; o[1] = ai[ii][jj];
+                }
+    }
+    b.sync();
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------------------
+// Workgroup GEMM on the f64 matrix cores for the dense contractions of the derivative kernels (C = J J^T, M = J^-1 J', the
+// N x N x 16 adjoint products): C(row, col) = sum_k fa(row, k) fb(k, col), rows < M, cols < Nc, k < K.  One wave per 16 x 16 tile,
+// tiles dealt round-robin to the waves; the operands come straight from wherever the functors read them (LDS, or the L2-resident
+// workspace), one double per lane and MFMA -- fine for these sizes (K <= 128), with the k loop unrolled for loads in flight.
+// fc(row, col, value) stores.  v_mfma_f64_16x16x4: A lane l -> (row l & 15, k l >> 4), B lane l -> (k l >> 4, col l & 15),
+// C/D lane l -> rows (l >> 4) + 4 r, col l & 15.  Host shim: the plain triple loop.
+// ------------------------------------------------------------------------------------------------------------
+template <class FA, class FB, class FC>
+CG_DEVI void cg_gemm_wg(const CgBlk& b, int M, int Nc, int K, FA fa, FB fb, FC fc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef double d4_t __attribute__((ext_vector_type(4)));
+    const int lane = b.tid & 63, col = lane & 15, kq = lane >> 4, wave = b.tid >> 6, nw = b.nthr >> 6;
+    const int tm = (M + 15) >> 4, tn = (Nc + 15) >> 4;
+    for (int t = wave; t < tm * tn; t += nw) {
+        const int ti = t / tn, tj = t - ti * tn;
+        const int ra = 16 * ti + col, cb = 16 * tj + col;
+        const bool aok = ra < M, bok = cb < Nc;
+        d4_t c = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + kq;
+            const bool kok = k < K;
+            const double av = (aok && kok) ? fa(ra, k) : 0.0;
+            const double bv = (bok && kok) ? fb(k, cb) : 0.0;
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, c, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * ti + kq + 4 * r;
+            if (rr < M && bok) fc(rr, cb, c[r]);
+        }
+    }
+#else
+    for (int e = b.tid; e < M * Nc; e += b.nthr) {
+        const int r = e / Nc, c = e - r * Nc;
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += fa(r, k) * fb(k, c);
+        fc(r, c, acc);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Wave-level LU, 2-D lane layout (gfx950): the sampler's determinants at N = n*d <= 32, n <= 16.
 //   real    : lane = 2 r + c holds row r, columns j = 2 m + c  (m < NMAX/2)   -> 2 N of 64 lanes busy, N/2 doubles each
 //   complex : lane = 4 r + c holds row r, columns j = 4 m + c  (m < 4)        -> 4 n of 64 lanes busy

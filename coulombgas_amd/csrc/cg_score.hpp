@@ -213,22 +213,11 @@ struct CgScore {
             }
             Upb[e] = acc;
         }
-        for (int e = b.tid; e < N * HS; e += b.nthr) {             // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]
-            const int r = e / HS, g = e - r * HS;
-            double acc = 0;
-            for (int k = 0; k < n; ++k)
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) acc += Jhat[r * N + k * D + bb] * G[F::iG(k, g, bb)];
-            Bb[e] = acc;
-        }
-        for (int e = b.tid; e < n * HS * D; e += b.nthr) {         // Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]
-            const int k = e / (HS * D), r = e - k * HS * D, g = r / D, bb = r - g * D;
-            double acc = 0;
-            for (int i = 0; i < n; ++i)
-#pragma unroll
-                for (int a = 0; a < D; ++a) acc += Jhat[(i * D + a) * N + k * D + bb] * Bm[F::iB(i, a, g)];
-            Gb[e] = acc;
-        }
+        // Bbar_i[a][g] = sum_k sum_b Jhat_ik[a][b] G_k[g][b]  and  Gbar_k[g][b] = sum_i sum_a Jhat_ik[a][b] B_i[a][g]: (N x N)(N x 16) on MFMA
+        cg_gemm_wg(b, N, HS, N, [&](int r, int c) { return Jhat[r * N + c]; }, [&](int c, int g) { return G[F::iG(c / D, g, c % D)]; },
+                   [&](int r, int g, double v) { Bb[r * HS + g] = v; });
+        cg_gemm_wg(b, N, HS, N, [&](int c, int r) { return Jhat[r * N + c]; }, [&](int r, int g) { return Bm[F::iB(r / D, r % D, g)]; },
+                   [&](int c, int g, double v) { Gb[((c / D) * HS + g) * D + (c % D)] = v; });
         {   // (J5) pair pass in (i,h) layout: Vbar_i[:,h] and the sigma_t / q_t adjoints -> partial Wtbar / btbar (Jacobian part)
             double pw[KT];
 #pragma unroll
@@ -345,15 +334,9 @@ struct CgScore {
         }
         b.sync();
         // (J2) Rbar_i[a][h] = sum_g Ubar Wa[g][h] + Bbar Wb[g][h] + (1/n) Vbar Wc[g][h]
-        for (int e = b.tid; e < N * HS; e += b.nthr) {
-            const int r = e / HS, h = e - r * HS;
-            double acc = 0;
-#pragma unroll
-            for (int g = 0; g < HS; ++g) acc += Ub[r * HS + g] * th[F::o_Wa + g * HS + h] + Bb[r * HS + g] * th[F::o_Wb + g * HS + h];
-#pragma unroll
-            for (int g = 0; g < HT; ++g) acc += rn * Vb[r * HT + g] * th[F::o_Wc + g * HS + h];
-            Rb[e] = acc;
-        }
+        cg_gemm_wg(b, N, HS, 2 * HS + HT,       // one (N x (2 HS + HT))((2 HS + HT) x HS) product: the rows of Wa, Wb, Wc are consecutive in theta
+                   [&](int r, int k) { return k < HS ? Ub[r * HS + k] : k < 2 * HS ? Bb[r * HS + k - HS] : rn * Vb[r * HT + k - 2 * HS]; },
+                   [&](int k, int h) { return th[F::o_Wa + k * HS + h]; }, [&](int r, int h, double v) { Rb[r * HS + h] = v; });
         b.sync();
         // (J1) sg2bar_i[h] = sum_a Rbar_i[a][h] Wf[h][a];  (F8) s2bar_i[h] = sum_a Wf[h][a] zbar_i[a];  (F7) u2bar = s2bar sg2 + sg2bar sg2'
         for (int e = b.tid; e < n * HS; e += b.nthr) {

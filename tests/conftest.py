@@ -18,7 +18,7 @@ BENCH_DIST = {}
 
 
 def pytest_sessionstart(session):
-    expr = session.config.getoption("-m") or ""
+    expr = session.config.getoption("markexpr", default="") or ""
     if "gpu" not in expr or "not gpu" in expr:
         return
     try:
@@ -38,6 +38,7 @@ def pytest_sessionstart(session):
         BENCH_DIST.update(rc=r.returncode, out=r.stdout, err=r.stderr[-4000:])
     except Exception as e:                          # noqa: BLE001 -- reported by the test
         BENCH_DIST.update(rc=-1, out="", err=repr(e))
+    session.config._cg_bench_dist = BENCH_DIST      # (the test reads it from request.config: `tests.conftest` is another module object)
 
 
 @pytest.fixture(scope="session")

@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 
 from tests.common import orbitals, box_length
-from tests import conftest
 
 pytestmark = pytest.mark.gpu
 
@@ -80,11 +79,11 @@ def test_training_with_a_world1_rccl_communicator_equals_the_null_communicator()
     assert all(np.isfinite([float(v) for v in r.split()]).all() for r in out["rccl"][0])
 
 
-def test_bench_distributed_branch_under_torch_distributed_run():
+def test_bench_distributed_branch_under_torch_distributed_run(request):
     """bench.py's N > 1 code path, launched at session start (tests/conftest.py) as `python -m torch.distributed.run
     --nproc-per-node 1 bench.py --gpus 1` with CG_FORCE_DIST=1: NCCL(=RCCL) process group through torch for the rendezvous, the
     library's own communicator for the data path."""
-    r = conftest.BENCH_DIST
+    r = getattr(request.config, "_cg_bench_dist", None)
     assert r, "the session-start launch did not run (pytest -m gpu on a GPU box)"
     assert r["rc"] == 0, r["out"][-2000:] + r["err"]
     line = [l for l in r["out"].splitlines() if l.startswith("{")][-1]
