@@ -5,6 +5,7 @@ reference): inputs + expected outputs in fp64.  Run once in the build container;
   golden_n7_d3.npz    the reference tests' shape (tests/test_logpsi.py:30-31; depth 2, spsize = tpsize = 16), L = 1.234
   golden_n13_d2.npz   BASELINE configs 1-3 shape, init-like N(0,0.01^2) weights
   golden_n29_d2.npz   shipped trained flow parameters (data/n_29_..._rs_10.0, epoch 3000) on 2 shipped walkers
+  golden_n49_d2.npz   (--n49) shipped parameters + walkers of data/n_49_..._rs_10.0 (Emax 36); Hutchinson variants only
   golden_n57_d2.npz, golden_n29_d2_rs1.npz   (--large) BASELINE configs 5 and 4: shipped parameters + walkers of
                       data/n_57_..._rs_10.0 (Emax 49) and data/n_29_..._rs_1.0; Hutchinson variants only
 each: x, state_idx, theta, sp_indices -> z, J, half_logdetJ, logphi, grad/lap (exact), lap (Hutchinson-split and full for the
@@ -81,7 +82,17 @@ def make_large():
     make("golden_n29_d2_rs1.npz", n, 2, 16, 16, L, d["theta"], d["x"][:2], state_indices(rng, 2, n, sp.shape[0]), sp, 1.0, 5, exact=False)
 
 
+def make_n49():
+    """n = 49 / Emax = 36 (six shipped production runs, no BASELINE config): shipped parameters + walkers of data/n_49_..._rs_10.0"""
+    rng = np.random.default_rng(20261049)
+    d = np.load(os.path.join(HERE, "shipped_runs", "n49_rs10.0.npz"))
+    n = 49; L = box_length(n, 2); sp = orbitals(2, 36)
+    make("golden_n49_d2.npz", n, 2, 16, 16, L, d["theta"], d["x"][:2], state_indices(rng, 2, n, sp.shape[0]), sp, 10.0, 6, exact=False)
+
+
 if __name__ == "__main__":
+    if "--n49" in sys.argv:
+        make_n49(); sys.exit(0)
     if "--large" in sys.argv:
         make_large(); sys.exit(0)
     rng = np.random.default_rng(20261003)

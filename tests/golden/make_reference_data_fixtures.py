@@ -84,6 +84,34 @@ def shipped(n, rs, epoch, nwalk, out):
     print(out, x[:nwalk].shape, theta.shape, row)
 
 
+def shipped_run(n, rs, nwalk):
+    """One production run of data/n_*: a slice of the final walkers, the trained flow and Transformer parameters and the last
+    published data.txt row, in ONE npz under tests/golden/shipped_runs/ (all 18 runs: round-3 widening of the reference-held pin)."""
+    d = glob.glob("%s/data/n_%d_dim_2_rs_%s_*" % (REF, n, rs))[0]
+    pk = sorted(glob.glob(os.path.join(d, "epoch_*.pkl")))[-1]
+    epoch = int(os.path.basename(pk)[6:12])
+    ck = _Unpickler(open(pk, "rb")).load()
+    x = np.asarray(ck["x"]).reshape(-1, n, 2)
+    rows = np.loadtxt(os.path.join(d, "data.txt"))
+    pf, pv = ck["params_flow"], ck["params_van"]
+    theta = np.concatenate([np.asarray(pf[k][l]).ravel() for k in sorted(pf) for l in ("b", "w")])
+    flat = {"van|%s|%s" % (m, l): np.asarray(v) for m in pv for l, v in pv[m].items()}
+    Emax = int(os.path.basename(d).split("_Emax_")[1].split("_")[0])
+    os.makedirs(os.path.join(HERE, "shipped_runs"), exist_ok=True)
+    out = os.path.join(HERE, "shipped_runs", "n%d_rs%s.npz" % (n, rs))
+    np.savez_compressed(out, x=x[:nwalk], theta=theta, data_row=rows[epoch - 1], n=n, rs=float(rs), Emax=Emax, epoch=epoch,
+                        n_walkers_total=x.shape[0], **flat)
+    print(out, x[:nwalk].shape, os.path.getsize(out) // 1024, "KB", rows[epoch - 1][:4])
+
+
+def pretrained_free_energies():
+    """the pretrained free-fermion Transformers of n = 49 / 57 (data/freefermion/pretraining) with their last data.txt row"""
+    for n in (49, 57):
+        d = glob.glob("%s/data/freefermion/pretraining/n_%d_*/*" % (REF, n))[0]
+        van_fixture(os.path.join(d, "params_van.pkl"), None, "pretrained_van_n%d.npz" % n,
+                    {"data_row_last": np.loadtxt(os.path.join(d, "data.txt"))[-1]})
+
+
 def van_fixture(src_pkl, key, out, extra):
     """params_van of a shipped model (pretrained free-fermion model or a checkpoint) as flat npz: 'module|leaf' -> array."""
     ck = _Unpickler(open(src_pkl, "rb")).load()
@@ -94,6 +122,12 @@ def van_fixture(src_pkl, key, out, extra):
 
 
 if __name__ == "__main__":
+    if "--runs" in sys.argv:                   # round 3: all 18 production runs + the two larger pretrained models
+        for n, nw in ((29, 192), (49, 128), (57, 128)):
+            for rs in ("0.25", "0.5", "1.0", "3.0", "5.0", "10.0"):
+                shipped_run(n, rs, nw)
+        pretrained_free_energies()
+        sys.exit(0)
     d = glob.glob("%s/data/freefermion/pretraining/n_13_*/*" % REF)[0]
     van_fixture(os.path.join(d, "params_van.pkl"), None, "pretrained_van_n13.npz",
                 {"data_row_last": np.loadtxt(os.path.join(d, "data.txt"))[-1]})

@@ -1,0 +1,158 @@
+"""Reference-held known answers through the HIP path, round-3 widening (run with -m gpu): every production run the reference ships
+(`data/n_*/data.txt` final rows + `epoch_*.pkl`), the pretrained free-fermion models of the two larger systems, n = 49 / Emax = 36
+against oracle-generated golden vectors, and the shipped n = 57 Transformer against torch autograd through the oracle.
+Fixtures: tests/golden/shipped_runs/*.npz, pretrained_van_n49/57.npz (tests/golden/make_reference_data_fixtures.py --runs),
+golden_n49_d2.npz (tests/golden/make_golden_vectors.py --n49)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.common import orbitals, box_length, GOLDEN as GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+RUNS = sorted(os.path.basename(f)[:-4] for f in glob.glob(os.path.join(GOLDEN_DIR, "shipped_runs", "n*_rs*.npz")))
+
+
+def _van_of(z, prefix="van|"):
+    pv = {}
+    for k in z.files:
+        if k.startswith(prefix):
+            _, m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    return pv
+
+
+@pytest.mark.parametrize("run", RUNS)
+def test_every_shipped_run_reproduces_its_published_row(run):
+    """The 18 production runs of the reference (n = 29 / 49 / 57, rs = 0.25 ... 10): shipped Transformer density matrix (sampled on
+    the GPU) + shipped trained flow -> Metropolis chains from shipped walkers -> local energies (Hutchinson-split, device-resident
+    step).  E and F of the last published data.txt row are reproduced within 0.5 % (n = 29) / 1 % (n >= 49: the
+    v1-formulas-vs-shipped-data gap of SURVEY App. B6 grows with n) or 4 standard errors -- of this sample and of the published row
+    combined (the row carries its own error bars; n = 29, rs = 0.5 ends on a noisy epoch: sigma_F 0.31 against 0.03-0.11 of its
+    neighbours) -- whichever is larger.  K, V and the acceptance separately: within 1 % / 1 % / 0.01 for rs <= 1; for rs >= 3 only
+    loosely (12 % / 2 % / 0.04): there the published K and V are not reproduced by the v1 formulas with the shipped parameters
+    (App. B6: K +3 ... +11 %, V -1 ... -1.6 %, acceptance -0.01 ... -0.03, identical in the oracle), while their sum E is."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import DeviceArray
+    fix = np.load(os.path.join(GOLDEN_DIR, "shipped_runs", run + ".npz"))
+    n, rs, Emax, dim = int(fix["n"]), float(fix["rs"]), int(fix["Emax"]), 2
+    tol = 0.005 if n == 29 else 0.01
+    L, beta = box_length(n, dim), 1 / (4 * 0.15)
+    sp = orbitals(2, Emax)
+    pv = _van_of(fix)
+    vanm = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    flow = cg.FermiNet(2, 16, 16, L)
+    eng = flow.engine(n, dim, sp)
+    sampler, log_prob = cg.make_autoregressive_sampler(vanm, sp, n, sp.shape[0], engine=eng)
+    pf = flow.unravel(fix["theta"], dim)
+    logpsi0 = cg.make_logpsi(flow, sp, L)
+    logphi, logjac = cg.make_logphi_logjacdet(flow, sp, L)
+    logp = cg.make_logp(logpsi0)
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi0, hutchinson=True, logphi=logphi, logjacdet=logjac)
+    G = cg.kpoints(dim, 15)
+    Vconst = n * rs / L * cg.Madelung(dim, 10, G)
+    loss = cg.make_loss(log_prob, logpsi, lgl, 10, G, L, rs, Vconst, beta)
+    B = fix["x"].shape[0]
+    x = DeviceArray.from_numpy(eng, fix["x"])
+    key = np.random.SeedSequence(7)
+    rounds = 12
+    acc_m = {k: [] for k in ("E_mean", "E2_mean", "F_mean", "F2_mean", "K_mean", "V_mean")}
+    rate = 0.0
+    for it in range(rounds + 2):
+        key, sidx, x, acc = cg.sample_stateindices_and_x(key, sampler, pv, logp, x, pf, 50, 0.1, L)
+        if it >= 2:
+            obs, _, _ = loss(pv, pf, sidx, x, key)
+            rate += acc / rounds
+            for k in acc_m:
+                acc_m[k].append(obs[k])
+    row = fix["data_row"]                                          # epoch F F_std E E_std K K_std V V_std S S_std accept
+    ns = B * rounds
+    E, F = np.mean(acc_m["E_mean"]), np.mean(acc_m["F_mean"])
+    sE = np.sqrt(max(np.mean(acc_m["E2_mean"]) - E * E, 0.0) / ns); sF = np.sqrt(max(np.mean(acc_m["F2_mean"]) - F * F, 0.0) / ns)
+    E, F, sE, sF = E / rs ** 2, F / rs ** 2, sE / rs ** 2, sF / rs ** 2
+    print("run %s: E %.5f +- %.5f (published %.5f)  F %.5f +- %.5f (published %.5f)  K %.4f (%.4f)  V %.4f (%.4f)  accept %.3f (%.3f)"
+          % (run, E, sE, row[3], F, sF, row[1], np.mean(acc_m["K_mean"]) / rs ** 2, row[5], np.mean(acc_m["V_mean"]) / rs ** 2, row[7], rate, row[11]))
+    assert np.isfinite([E, F]).all() and 0.1 < rate < 0.7
+    assert abs(E - row[3]) < max(tol * abs(row[3]), 4 * np.hypot(sE, row[4])), (E, sE, row[3], row[4])
+    assert abs(F - row[1]) < max(tol * abs(row[1]), 4 * np.hypot(sF, row[2])), (F, sF, row[1], row[2])
+    K, V = np.mean(acc_m["K_mean"]) / rs ** 2, np.mean(acc_m["V_mean"]) / rs ** 2
+    tK, tV, tA = (0.01, 0.01, 0.01) if rs <= 1.0 else (0.12, 0.02, 0.04)
+    assert abs(K - row[5]) < tK * abs(row[5]) and abs(V - row[7]) < tV * abs(row[7]) and abs(rate - row[11]) < tA, (K, row[5], V, row[7], rate, row[11])
+    x.free()
+
+
+@pytest.mark.parametrize("n,Emax", [(49, 36), (57, 49)])
+def test_pretrained_free_fermion_models_of_the_larger_systems(n, Emax):
+    """data/freefermion/pretraining/n_49_* and n_57_*: the shipped pretrained Transformers, sampled and evaluated on the device
+    (cg_van_sample / cg_van_log_prob), reproduce the published F, E, S of their last data.txt row (91.902967 / 106.763204 ...)."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    z = np.load(os.path.join(GOLDEN_DIR, "pretrained_van_n%d.npz" % n))
+    pv = {}
+    for k in z.files:
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    dim = 2
+    L, beta = np.sqrt(np.pi * n), 1 / (4 * 0.15)
+    spt = orbitals(2, Emax)
+    Es = (2 * np.pi / L) ** 2 * (spt ** 2).sum(-1)                                    # src/freefermion/pretraining.py:54
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), spt)
+    van = cg.Transformer(spt.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, spt, n, spt.shape[0], engine=eng)
+    B = 32768
+    s_d = sampler(pv, 1, B)
+    s, lp = np.asarray(s_d), np.asarray(log_prob(pv, s_d))
+    assert (np.diff(s, axis=1) > 0).all() and s.min() >= 0 and s.max() < spt.shape[0]
+    Et = Es[s].sum(-1)
+    F = lp / beta + Et
+    row = z["data_row_last"]                                                          # epoch, F, F_std, E, E_std, S, S_std
+    print("pretrained n=%d on the device: F %.6f +- %.6f (published %.6f)  E %.4f (published %.4f)  S %.4f (published %.4f)"
+          % (n, F.mean(), F.std() / np.sqrt(B), row[1], Et.mean(), row[3], -lp.mean(), row[5]))
+    assert abs(F.mean() - row[1]) < 5 * np.hypot(F.std() / np.sqrt(B), row[2])
+    assert abs(Et.mean() - row[3]) < 5 * np.hypot(Et.std() / np.sqrt(B), row[4])
+    assert abs(-lp.mean() - row[5]) < 5 * np.hypot(lp.std() / np.sqrt(B), row[6])
+    eng.close()
+
+
+def test_n49_against_golden_vectors():
+    """n = 49 / Emax = 36 (N = 98: six shipped production runs, never exercised before round 3): cg_logpsi, cg_flow_jacobian,
+    cg_grad_laplacian (Hutchinson variants), cg_param_vjp, cg_ewald and the chain against the oracle's golden vectors."""
+    from coulombgas_amd.engine import Engine
+    from tests.test_host_emul import check_against_golden
+    check_against_golden(lambda *a: Engine(*a), "golden_n49_d2.npz")
+
+
+def test_shipped_n57_transformer_against_torch_autograd():
+    """The shipped n = 57 density matrix (M = 149 orbitals, 57 positions): log p and the per-sample scores of the device's forward
+    and reverse pass against torch autograd through the ORACLE's restatement of src/autoregressive.py + src/sampler.py (round 2
+    compared this model only with the numpy checker of the tests)."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    from coulombgas_amd.sr import ravel_pytree
+    from oracle import cg_ref as R
+    n, dim = 57, 2
+    sp49 = orbitals(2, 49)
+    z = np.load(os.path.join(GOLDEN_DIR, "shipped_n57_rs10_van.npz"))
+    pv = {}
+    for k in z.files:
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    eng = Engine(n, dim, 2, 16, 16, box_length(n, dim), sp49)
+    van = cg.Transformer(sp49.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp49, n, sp49.shape[0], engine=eng)
+    s_d = sampler(pv, 9, 8)
+    s = np.asarray(s_d)
+    lp_dev = np.asarray(log_prob(pv, s_d))
+    S = np.asarray(log_prob.grad(pv, s_d))                                    # (B, P) in ravel_pytree order
+    scale = np.abs(S).max()
+    for b in range(4):
+        tp = {m: {l: R.T(v).clone().requires_grad_(True) for l, v in pv[m].items()} for m in pv}
+        lp = R.autoregressive_log_prob(tp, torch.as_tensor(s[b].astype(np.int64)), R.T(sp49), 2, 4)
+        assert abs(float(lp) - lp_dev[b]) < 1e-11 * abs(float(lp))
+        lp.backward()
+        gref = ravel_pytree({m: {l: tp[m][l].grad.numpy() for l in tp[m]} for m in tp})[0]
+        assert np.abs(S[b] - gref).max() < 1e-11 * scale, (b, np.abs(S[b] - gref).max() / scale)
+    eng.close()

@@ -36,7 +36,7 @@ def check_against_golden(eng_factory, name, tol=1e-10, exact=True):
 
 
 @pytest.mark.parametrize("name", ["golden_n7_d3.npz", "golden_n13_d2.npz", "golden_n29_d2.npz", "golden_n29_d2_rs1.npz",
-                                  "golden_n57_d2.npz"])
+                                  "golden_n49_d2.npz", "golden_n57_d2.npz"])
 def test_device_code_on_host_vs_golden(name):
     check_against_golden(EmulEngine, name)
 
