@@ -175,7 +175,18 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1],)))
         return unflat_params(network, eng.to_host(g), sp_indices.shape[1])
 
-    log_prob.grad, log_prob.vjp = grad, vjp
+    def vjp_pair_d(params, state_idx, w1, w2):
+        """both weighted sums jax.jacrev(classical_lossfn) needs (main.py:277) in ONE device buffer [sum_b w1[b] S_b | sum_b w2[b] S_b]
+        (flat parameter order): the caller all-reduces it in place (main.py:280) before anything is read back."""
+        eng = _dev_scores(params, state_idx)
+        Pv = DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1]
+        out = eng.scratch("van_vjp_pair", (2 * Pv,))
+        for k, w in enumerate((w1, w2)):
+            w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w%d" % k)
+            eng.van_scores_vjp_d(w_d, eng.view(out, k * Pv, (Pv,)))
+        return out, (lambda flat: unflat_params(network, flat, sp_indices.shape[1]))
+
+    log_prob.grad, log_prob.vjp, log_prob.vjp_pair_d = grad, vjp, vjp_pair_d
 
     def attach(engine):
         dev["engine"] = engine

@@ -109,12 +109,21 @@ def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, lo
         grad_flow, score_flow = quantum_lossfn.grad(params_flow, reduce=True)          # :278 + the pmean of :280 on the device
         grad_van = score_van = None
         if log_prob_vjp is not None and params_van is not None:                        # :277
-            classical_lossfn(params_van)
-            grad_van = log_prob_vjp(params_van, state_indices, classical_lossfn.weights)
-            score_van = log_prob_vjp(params_van, state_indices, classical_lossfn.score_weights)
-            flat, unravel = _sr.ravel_pytree({"g": grad_van, "s": score_van})
-            tree = unravel(cm.pmean(flat))                                             # :280 (classical part, host model)
-            grad_van, score_van = tree["g"], tree["s"]
+            pair = getattr(getattr(log_prob_vjp, "__self__", None), "vjp_pair_d", None) or getattr(log_prob_vjp, "pair_d", None)
+            if pair is not None and _is_device(x):
+                # device density matrix: clip weights, both weighted score sums and their pmean (:280) without leaving HBM
+                classical_lossfn(params_van, values=False)
+                buf, unflat = pair(params_van, state_indices, classical_lossfn.weights, classical_lossfn.score_weights)
+                cm.pmean_d(buf)
+                h = np.asarray(buf); Pv = h.size // 2
+                grad_van, score_van = unflat(h[:Pv]), unflat(h[Pv:])
+            else:
+                classical_lossfn(params_van)
+                grad_van = log_prob_vjp(params_van, state_indices, classical_lossfn.weights)
+                score_van = log_prob_vjp(params_van, state_indices, classical_lossfn.score_weights)
+                flat, unravel = _sr.ravel_pytree({"g": grad_van, "s": score_van})
+                tree = unravel(cm.pmean(flat))                                         # :280 (classical part, host model)
+                grad_van, score_van = tree["g"], tree["s"]
         grads = grad_flow if grad_van is None else {"v": grad_van, "f": grad_flow}
         scores = score_flow if score_van is None else {"v": score_van, "f": score_flow}
         acc["data"] = {k: acc["data"][k] + data[k] for k in DATA_KEYS}                 # :281-283
@@ -168,6 +177,8 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
     cm = comm or get_comm()
     if log_prob_vjp is None and hasattr(log_prob, "vjp"):          # make_autoregressive_sampler's log_prob carries its own
         log_prob_vjp = log_prob.vjp                                 # reverse pass: the density matrix is trained as well
+        if hasattr(log_prob, "vjp_pair_d"):
+            log_prob_vjp.pair_d = log_prob.vjp_pair_d
         if classical_score_fn is None and hasattr(log_prob, "grad"):
             classical_score_fn = log_prob.grad
     G = kpoints(dim, Gmax)

@@ -74,14 +74,19 @@ def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, 
                 cache["tvE"] = cm.pmean_d(eng.abs_dev_d(Eloc, (mom, _I_E), "tv_E"))
             return cache["tvE"]
 
-        def classical_lossfn(params_van):
+        def classical_lossfn(params_van, values=True):
+            """src/VMC.py:60-67.  The clip width, the clipped F_loc and the weights d gradF_phi / d logp_states[b] = F_clip[b] / B are
+            formed on the device (cg_abs_dev / cg_clip_weights in their real-valued mode, the pmean of :63 in place on the device
+            scalar): F_loc never visits the host.  values=False (the driver: only .weights / .score_weights are used) skips the
+            two O(B) read-backs the returned pair needs."""
+            tvF = cm.pmean_d(eng.abs_dev_d(Floc, (mom, _I_F), "tv_F"))                        # :63
+            w, _ = eng.clip_weights_d(Floc, (mom, _I_F), tvF, 1.0 / B, "wF")                  # clip(F_loc, <F> -+ 5 tv) / B
+            classical_lossfn.weights = w
+            classical_lossfn.score_weights = eng.asdevice(np.full(B, 1.0 / B), "w_uniform")
+            if not values:
+                return None, None
             lps = np.asarray(log_prob(params_van, state_indices), dtype=np.float64)
-            Floc_h = eng.to_host(Floc)
-            tv = cm.pmean(float(np.abs(Floc_h - F_mean).mean()))                           # :63
-            Floc_clipped = np.clip(Floc_h, F_mean - 5.0 * tv, F_mean + 5.0 * tv)
-            classical_lossfn.weights = Floc_clipped / B      # d gradF_phi / d logp_states[b]
-            classical_lossfn.score_weights = np.full(B, 1.0 / B)
-            return float((lps * Floc_clipped).mean()), float(lps.mean())
+            return float(lps @ eng.to_host(w)), float(lps.mean())
 
         def quantum_lossfn(params_flow):
             """(gradF_theta, quantum_score) values of :69-76 (diagnostic path: downloads log Psi and E_loc)"""
