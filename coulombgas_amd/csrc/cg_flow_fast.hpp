@@ -588,11 +588,14 @@ struct CgFast {
         double* wfl = wt + HT * (P + 1);
         if (!w.wt_resident) stage_wt(b, th, lds, o);
         CG_STAMP(4)
+#if !defined(CG_EXP_NO_DENSE)       /* timing experiment (garbage numbers): the MFMA dense phases free -- the bound on pipelining them */
         jac_factors_mfma<0>(b, w, n, lds, o, wfl);
+#endif
         CG_STAMP(5)
         g_pass_mfma(b, w, n, L, lds, o);
         b.sync();
         CG_STAMP(6)
+#if !defined(CG_EXP_NO_DENSE)
         jac_up_mfma(b, w, n, lds, o);
         b.sync();
         CG_STAMP(7)
@@ -600,6 +603,7 @@ struct CgFast {
         b.sync();
         CG_STAMP(8)
         jac_factors_mfma<1>(b, w, n, lds, o, wfl);
+#endif
         b.sync();
         CG_STAMP(9)
         for (int e = b.tid; e < n * n; e += b.nthr) {
@@ -629,7 +633,12 @@ struct CgFast {
                     u += wc * pf.c2[a] + ws * pf.s2[a];
                     q[a] = wc * tc[a] + ws * ts[a] + wd * td[a];
                 }
+#if defined(CG_EXP_FREE_SIGMA)      /* timing experiment (garbage numbers): what a CACHED sigmoid would cost -- an upper bound on what sharing
+                                       the exponential of the primal pass with this pass can gain (profiles/r03*_experiments.txt) */
+                const double sg = 0.25 + 1e-3 * u;
+#else
                 const double sg = sigmoid_only(u);
+#endif
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
                     const double vs = V[iV(i, a, h)] * sg;
@@ -787,6 +796,9 @@ struct CgFast {
         CG_STAMP(2)
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+#if defined(CG_EXP_NO_DENSE)
+            if (wf) { for (int e = b.tid; e < n * D; e += b.nthr) z[e] = x[e] + 1e-3 * m1[e]; b.sync(); CG_STAMP(3) return; }
+#endif
             if (wf) { primal_dense_mfma(b, *wf, (const double*)x, n, (double*)lds, o); CG_STAMP(3) return; }
         }
 #endif
@@ -1019,8 +1031,12 @@ struct CgFast {
             if (b.nthr == 64 && (n == 13 || n == 16) && n * D == 2 * n) {
                 // single-wave workgroup: both factorisations interleaved in one instruction stream
                 double lr, l2, a2;
+#if defined(CG_EXP_NO_LU)           /* timing experiment (garbage numbers): both factorisations free -- the bound on any LU speed-up */
+                lr = lds[o.J] + lds[o.J + 27]; l2 = lds[o.Dm]; a2 = lds[o.Dm + 1];
+#else
                 if (n == 13) cg_wave_lu2_both<26, 13>(lds + o.J, 2 * n, 2 * n, lds + o.lus, lds + o.Dm, n, n, lds + o.lus + 32, lr, l2, a2);
                 else cg_wave_lu2_both<32, 16>(lds + o.J, 2 * n, 2 * n, lds + o.lus, lds + o.Dm, n, n, lds + o.lus + 32, lr, l2, a2);
+#endif
                 half_logdetJ = 0.5 * lr; la = l2; ar = a2;
                 CG_STAMP(13)
                 CG_STAMP(14)
