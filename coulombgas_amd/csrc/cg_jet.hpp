@@ -37,9 +37,29 @@ CG_DEVI void cg_sincos(Jet2 a, Jet2& s, Jet2& c, bool = false) {
     s = jet_chain(a, sv, cv, -sv); c = jet_chain(a, cv, -sv, -cv);
 }
 CG_DEVI double cg_sqrt(double a) { return sqrt(a); }
-CG_DEVI Jet2 cg_sqrt(Jet2 a) { const double r = sqrt(a.v), ri = 1.0 / r; return jet_chain(a, r, 0.5 * ri, -0.25 * ri / a.v); }
 CG_DEVI double cg_rcp(double a) { return 1.0 / a; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// jets of sqrt and 1/x from v_rsq_f64 / v_rcp_f64 + Newton steps (~1 ulp) instead of the IEEE sqrt and two divisions (~80
+// instructions per pair feature of the directional passes)
+CG_DEVI Jet2 cg_sqrt(Jet2 a) {
+    double y = __builtin_amdgcn_rsq(a.v);
+    const double hx = 0.5 * a.v;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    const double g = a.v * y;
+    const double r = fma(fma(-g, g, a.v), 0.5 * y, g);           // sqrt(v), ri = y = 1 / sqrt(v)
+    return jet_chain(a, r, 0.5 * y, -0.25 * y * (y * y));
+}
+CG_DEVI Jet2 cg_rcp(Jet2 a) {
+    double r = __builtin_amdgcn_rcp(a.v);
+    r = fma(r, fma(-a.v, r, 1.0), r);
+    r = fma(r, fma(-a.v, r, 1.0), r);
+    return jet_chain(a, r, -r * r, 2.0 * r * (r * r));
+}
+#else
+CG_DEVI Jet2 cg_sqrt(Jet2 a) { const double r = sqrt(a.v), ri = 1.0 / r; return jet_chain(a, r, 0.5 * ri, -0.25 * ri / a.v); }
 CG_DEVI Jet2 cg_rcp(Jet2 a) { const double r = 1.0 / a.v; return jet_chain(a, r, -r * r, 2.0 * r * r * r); }
+#endif
 CG_DEVI void cg_softplus_sigmoid(double u, double& sp, double& sg) { softplus_sigmoid(u, sp, sg); }
 CG_DEVI void cg_softplus_sigmoid(Jet2 u, Jet2& sp, Jet2& sg) {
     double s, g; softplus_sigmoid(u.v, s, g);

@@ -64,6 +64,7 @@ struct CgLap {
         int da, pt, kocc, Jc, Dc, Dinv, perm, C;
         int Jhat, Upb, Vb, Bb, Gb, sg1b, sg2b, Ub, Rb, u2b, u1b, s1b, m1b, gbb, su2, m0b, rbar;
         int Lm0, gu1, Ls1, Lm1, Lgb, Am, Hk, SQ, Er, Su2, Ls2;
+        int eLm0, egu1, eLm1;              // the forward Laplacian's pair sums when formed early (by the waves that idle during the inverses)
         // B
         int ja, xj, M, M_in_arena;
         unsigned lds_total, ws_total;      // doubles
@@ -121,6 +122,8 @@ struct CgLap {
         l.Jc = take(NN); l.Dc = take(nn2); l.Dinv = take(nn2); l.perm = take(N + 42);
         // T^a, diag K^ab live from the set-up to the Slater part only (modes 0, 2): behind the set-up scratch, under the adjoints
         if (!l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
+        // behind everything the set-up, the Slater part and the forward Laplacian use (the reverse sweep, which runs last, overlays it)
+        l.eLm0 = take((size_t)n * P); l.egu1 = take((size_t)n * HS); l.eLm1 = take((size_t)n * HT);
         size_t A_size = t;
         t = A2; l.C = take(NN); A_size = t > A_size ? t : A_size;
         t = A1;
@@ -221,7 +224,7 @@ struct CgLap {
     template <bool AL>
     static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                              const Mem<AL>& mem, const Lay& l) {
+                              const Mem<AL>& mem, const Lay& l, bool& early /* in: wanted; out: done */) {
         const int N = n * D;
         const CgFastLds& o = l.o;
         double* da = mem.a + l.da; double* x = mem.p + l.x;
@@ -246,8 +249,9 @@ struct CgLap {
         CG_STAMP_END(26)
         CG_STAMP_START(27)
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
-        bool inverted = false;
+        bool inverted = false, early_done = false;
 #if defined(__HIP_DEVICE_COMPILE__)
+        early = early && b.nthr >= 192;
         if (N <= 32 && n <= 16 && b.nthr >= 128 && N * N + 2 * n * n >= 128) {      // (the Jc + Dc slots are the 128-double scratch)
             // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (no barriers, J and D intact)
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
@@ -258,11 +262,20 @@ struct CgLap {
             } else if (wave == 1) {
                 if (n == 13) cg_wave_inverse_complex<13>(da + o.Dm, n, n, Dinv, n, Jc + 64);
                 else cg_wave_inverse_complex<16>(da + o.Dm, n, n, Dinv, n, Jc + 64);
+            } else if (early) {
+                // the other waves, meanwhile: what needs neither inverse -- the pair sums of the forward Laplacian and C = J J^T
+                const CgBlk b2{b.tid - 128, b.nthr - 128};
+                fwd_pair_sums(b2, th, n, L, mem.a + l.pt, mem.a + l.eLm1, mem.a + l.eLm0, mem.a + l.egu1);
+                const double* J = da + o.J; double* C = mem.a + l.C;
+                cg_gemm_wg(b2, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
+                           [&](int r, int c, double v) { C[r * N + c] = v; });
             }
             b.sync();
             inverted = true;
+            early_done = early;
         }
 #endif
+        early = early_done;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (!inverted && l.stage_lds && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
             // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
@@ -340,7 +353,7 @@ struct CgLap {
     // ------------------------------------------------------------------------------------------------------
     template <bool AL>
     static CG_DEVI void slater_part(const CgBlk& b, int n, const Mem<AL>& mem, const Lay& l, bool want_lap,
-                                    double* __restrict__ grad /*N x 2, global*/, double& p_re, double& p_im) {
+                                    double* __restrict__ grad /*N x 2, global*/, double& p_re, double& p_im, bool have_C = false) {
         const int N = n * D;
         const double* J = mem.a + l.da + l.o.J; const double* gz = mem.p + l.gz;
         const double* Ta = (l.TaKd_in_P ? mem.p : mem.a) + l.Ta; const double* Kd = (l.TaKd_in_P ? mem.p : mem.a) + l.Kd;
@@ -352,9 +365,11 @@ struct CgLap {
         }
         p_re = 0; p_im = 0;
         if (!want_lap) return;
-        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
-                   [&](int r, int c, double v) { C[r * N + c] = v; });          // C = J J^T (matrix cores)
-        b.sync();
+        if (!have_C) {
+            cg_gemm_wg(b, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
+                       [&](int r, int c, double v) { C[r * N + c] = v; });      // C = J J^T (matrix cores)
+            b.sync();
+        }
         for (int e = b.tid; e < n * D * D; e += b.nthr) {
             const int i = e / (D * D), r = e - i * D * D, a = r / D, bb = r - a * D;
             const double c = C[(i * D + a) * N + i * D + bb];
@@ -645,6 +660,75 @@ struct CgLap {
     //   lap sp(u) = sig(u) lap u + sig'(u) |grad u|^2
     // Pair features depend on r = x_i - x_j only: lap_x f(r) = 2 lap_r f, |grad_x f|^2 = 2 |grad_r f|^2.
     // ------------------------------------------------------------------------------------------------------
+    // The two pair sums of the forward Laplacian that depend on the pair table and the weights only (not on J^-1, D^-1): lap m1, lap m0
+    // and |grad u1|^2.  Called by the whole workgroup, or -- early -- by the waves that would idle while two waves invert J and D.
+    static CG_DEVI void fwd_pair_sums(const CgBlk& b, const double* th, int n, double L, const double* PT, double* Lm1, double* Lm0, double* gu1) {
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
+        // pair pass, item (i,h): lap m1_i[h], lap m0_i[f], |grad u1_i[h]|^2
+        for (int e = b.tid; e < n * HM; e += b.nthr) {
+            const int i = e / HM, h = e - i * HM;
+            const bool do_t = h < HT;
+            double wt[P], bt = 0.0;
+#pragma unroll
+            for (int f = 0; f < P; ++f) wt[f] = do_t ? th[F::o_t0w + f * HT + h] : 0.0;
+            if (do_t) bt = th[F::o_t0b + h];
+            double acc = 0.0, raw = 0.0;
+#pragma unroll CG_UNR_K
+            for (int j = 0; j < n; ++j) {
+                if (j == i) continue;
+                PairT t; pt_load(PT, i * n + j, c1, c2c, t);
+                double l0d = 0.0;                                   // lap_r of the norm feature
+#pragma unroll
+                for (int a = 0; a < D; ++a) l0d += pl2 * t.c2[a] - t.td[a] * t.td[a];
+                l0d *= t.rdel;
+                if (do_t) {
+                    double u = bt + wt[2 * D] * t.del, lu = wt[2 * D] * l0d, gsq = 0.0;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double wf = wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
+                        u += wf; lu -= c1 * c1 * wf;
+                        const double q = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
+                        gsq += q * q;
+                    }
+                    const double sg = sigmoid_only(u);
+                    acc += 2.0 * (sg * lu + sg * (1.0 - sg) * gsq);
+                }
+                if (h < P) {
+                    double fv = l0d;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) { if (h == a) fv = -c1 * c1 * t.c2[a]; if (h == D + a) fv = -c1 * c1 * t.s2[a]; }
+                    raw += 2.0 * fv;
+                }
+            }
+            if (do_t) Lm1[i * HT + h] = acc * rn;
+            if (h < P) Lm0[i * P + h] = raw * rn;
+        }
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            double w_c[D], w_s[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
+            const double w_d = th[F::o_W0 + 2 * D * HS + h];
+            double ssq = 0.0, sq[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) sq[a] = 0.0;
+#pragma unroll CG_UNR_Q
+            for (int k = 0; k < n; ++k) {
+                if (k == i) continue;
+                PairT t; pt_load(PT, i * n + k, c1, c2c, t);
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
+                    ssq += q0 * q0; sq[bb] += q0;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) ssq += sq[a] * sq[a];
+            gu1[e] = ssq * rn * rn;
+        }
+    }
+
 #if defined(__HIP_DEVICE_COMPILE__)
     // |grad_x u2_i[h]|^2 on the matrix cores (spsize = tpsize = 16).  For one particle i the dense x-gradient of the last layer's
     // pre-activations is  E_ik[h][b] = H_k[h][b] - (1/n) (A_i T_ik)[h][b] - (1/n) sum_g Wc[g][h] sig_t(u_ik[g]) q_ik[g][b]  (k != i),
@@ -747,14 +831,15 @@ struct CgLap {
 
     template <bool AL>
     static CG_DEVI void forward_laplacian(const CgBlk& b, const double* __restrict__ th, int n, double L, const Mem<AL>& mem,
-                                          const Lay& l, double& q_re, double& q_im) {
+                                          const Lay& l, double& q_re, double& q_im, bool pre = false) {
         const CgFastLds& o = l.o;
         const double* da = mem.a + l.da;
         const double *sg1 = da + o.sg1, *sg2 = da + o.sg2, *G = da + o.G;
         const double* PT = mem.a + l.pt;
         const double* gz = mem.p + l.gz;
-        double *Lm0 = mem.a + l.Lm0, *gu1 = mem.a + l.gu1, *Ls1 = mem.a + l.Ls1, *Lm1 = mem.a + l.Lm1, *Lgb = mem.a + l.Lgb, *Am = mem.a + l.Am,
-               *Hk = mem.a + l.Hk, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
+        // pre: the pair sums were formed during the set-up (fwd_pair_sums by the idle waves) and wait behind the set-up scratch
+        double *Lm0 = mem.a + (pre ? l.eLm0 : l.Lm0), *gu1 = mem.a + (pre ? l.egu1 : l.gu1), *Lm1 = mem.a + (pre ? l.eLm1 : l.Lm1);
+        double *Ls1 = mem.a + l.Ls1, *Lgb = mem.a + l.Lgb, *Am = mem.a + l.Am, *Hk = mem.a + l.Hk, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
         bool mfma_path = false;
@@ -762,68 +847,7 @@ struct CgLap {
         if constexpr (HS == 16 && HT == 16) mfma_path = true;
 #endif
 
-        // pair pass, item (i,h): lap m1_i[h], lap m0_i[f], |grad u1_i[h]|^2
-        for (int e = b.tid; e < n * HM; e += b.nthr) {
-            const int i = e / HM, h = e - i * HM;
-            const bool do_t = h < HT;
-            double wt[P], bt = 0.0;
-#pragma unroll
-            for (int f = 0; f < P; ++f) wt[f] = do_t ? th[F::o_t0w + f * HT + h] : 0.0;
-            if (do_t) bt = th[F::o_t0b + h];
-            double acc = 0.0, raw = 0.0;
-#pragma unroll CG_UNR_K
-            for (int j = 0; j < n; ++j) {
-                if (j == i) continue;
-                PairT t; pt_load(PT, i * n + j, c1, c2c, t);
-                double l0d = 0.0;                                   // lap_r of the norm feature
-#pragma unroll
-                for (int a = 0; a < D; ++a) l0d += pl2 * t.c2[a] - t.td[a] * t.td[a];
-                l0d *= t.rdel;
-                if (do_t) {
-                    double u = bt + wt[2 * D] * t.del, lu = wt[2 * D] * l0d, gsq = 0.0;
-#pragma unroll
-                    for (int a = 0; a < D; ++a) {
-                        const double wf = wt[a] * t.c2[a] + wt[D + a] * t.s2[a];
-                        u += wf; lu -= c1 * c1 * wf;
-                        const double q = wt[a] * t.tc[a] + wt[D + a] * t.ts[a] + wt[2 * D] * t.td[a];
-                        gsq += q * q;
-                    }
-                    const double sg = sigmoid_only(u);
-                    acc += 2.0 * (sg * lu + sg * (1.0 - sg) * gsq);
-                }
-                if (h < P) {
-                    double fv = l0d;
-#pragma unroll
-                    for (int a = 0; a < D; ++a) { if (h == a) fv = -c1 * c1 * t.c2[a]; if (h == D + a) fv = -c1 * c1 * t.s2[a]; }
-                    raw += 2.0 * fv;
-                }
-            }
-            if (do_t) Lm1[i * HT + h] = acc * rn;
-            if (h < P) Lm0[i * P + h] = raw * rn;
-        }
-        for (int e = b.tid; e < n * HS; e += b.nthr) {
-            const int i = e / HS, h = e - i * HS;
-            double w_c[D], w_s[D];
-#pragma unroll
-            for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
-            const double w_d = th[F::o_W0 + 2 * D * HS + h];
-            double ssq = 0.0, sq[D];
-#pragma unroll
-            for (int a = 0; a < D; ++a) sq[a] = 0.0;
-#pragma unroll CG_UNR_Q
-            for (int k = 0; k < n; ++k) {
-                if (k == i) continue;
-                PairT t; pt_load(PT, i * n + k, c1, c2c, t);
-#pragma unroll
-                for (int bb = 0; bb < D; ++bb) {
-                    const double q0 = w_c[bb] * t.tc[bb] + w_s[bb] * t.ts[bb] + w_d * t.td[bb];
-                    ssq += q0 * q0; sq[bb] += q0;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < D; ++a) ssq += sq[a] * sq[a];
-            gu1[e] = ssq * rn * rn;
-        }
+        if (!pre) fwd_pair_sums(b, th, n, L, PT, Lm1, Lm0, gu1);
         // per-particle factors of the dense x-gradient of u2:  A_i = Wa^T diag(sg1_i) W0^T (HS x P),  H_k = Wb^T G_k (HS x D)
         if (mfma_path) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1019,27 +1043,29 @@ struct CgLap {
                                        double* __restrict__ lap /*2*/, double* lds, double* ws, const Lay& l) {
         const int N = n * D;
         const Mem<AL> mem(lds, ws, l);
-        CG_STAMP_START(20)
-        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l);
-        CG_STAMP_END(20)
         const bool exact_phi = mode != 1;
+        bool early = exact_phi;                      // (set-up: granted on the wave-inverse path with waves to spare)
+        CG_STAMP_START(20)
+        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l, early);
+        CG_STAMP_END(20)
         double s_re, s_im, q_re = 0, q_im = 0;
         CG_STAMP_START(21)
-        slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im);      // grad <- J^T g
-        b.sync();                                                        // Jhat overlays J, the adjoints overlay C
+        slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im, early);      // grad <- J^T g
+        b.sync();                                                        // the forward Laplacian's arrays overlay J and C
         CG_STAMP_END(21)
+        CG_STAMP_START(23)
+        if (exact_phi) forward_laplacian<AL>(b, th, n, L, mem, l, q_re, q_im, early);
+        double tot[4] = {s_re + q_re, s_im + q_im, 0.0, 0.0};
+        b.sync();                                                        // the adjoints overlay the forward Laplacian's arrays
+        CG_STAMP_END(23)
         CG_STAMP_START(22)
         reverse_x<AL>(b, th, n, L, mem, l);
         {
             const double* xbar = mem.p + l.xbar;
             for (int e = b.tid; e < N; e += b.nthr) grad[2 * e] += xbar[e];   // same thread wrote grad[2 e] above
         }
-        CG_STAMP_END(22)
-        CG_STAMP_START(23)
-        if (exact_phi) forward_laplacian<AL>(b, th, n, L, mem, l, q_re, q_im);
-        double tot[4] = {s_re + q_re, s_im + q_im, 0.0, 0.0};
         b.sync();                                    // the jet arena overlays the primal arena
-        CG_STAMP_END(23)
+        CG_STAMP_END(22)
         CG_STAMP_START(24)
         if (mode == 0) {
             for (int dir = 0; dir < N; ++dir) {
