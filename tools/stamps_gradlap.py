@@ -28,10 +28,11 @@ eng.grad_laplacian(x, sidx, mode, v)
 fn(eng._ctx, buf.ctypes.data, 1)
 cyc = buf.astype(np.int64).astype(np.float64)
 tot = sum(cyc[k] for k in NAMES)
-print("n=%d B=%d mode=%d: wave-cycles per walker by phase (4 waves per workgroup):" % (n, B, mode))
+W = 4 if n <= 16 else 8                # waves per workgroup of the launch (256 threads all-LDS / 512 threads)
+print("n=%d B=%d mode=%d: wave-cycles per walker by phase (%d waves per workgroup):" % (n, B, mode, W))
 for k, nm in NAMES.items():
-    print("  %2d %-36s %10.0f  %5.1f %%" % (k, nm, cyc[k] / B / 4, 100 * cyc[k] / tot))
-print("  total %.0f cycles per walker per wave" % (tot / B / 4))
+    print("  %2d %-36s %10.0f  %5.1f %%" % (k, nm, cyc[k] / B / W, 100 * cyc[k] / tot))
+print("  total %.0f cycles per walker per wave" % (tot / B / W))
 for k, nm in SUB.items():
     if cyc[k]:
-        print("  %2d %-44s %10.0f  %5.1f %% of the kernel" % (k, nm, cyc[k] / B / 4, 100 * cyc[k] / tot))
+        print("  %2d %-44s %10.0f  %5.1f %% of the kernel" % (k, nm, cyc[k] / B / W, 100 * cyc[k] / tot))
