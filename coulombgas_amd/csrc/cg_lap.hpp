@@ -122,8 +122,7 @@ struct CgLap {
         l.Jc = take(NN); l.Dc = take(nn2); l.Dinv = take(nn2); l.perm = take(N + 42);
         // T^a, diag K^ab live from the set-up to the Slater part only (modes 0, 2): behind the set-up scratch, under the adjoints
         if (!l.TaKd_in_P) { l.Ta = take(2 * (size_t)D * n * n); l.Kd = take(2 * (size_t)D * D * n); }
-        // behind everything the set-up, the Slater part and the forward Laplacian use (the reverse sweep, which runs last, overlays it)
-        l.eLm0 = take((size_t)n * P); l.egu1 = take((size_t)n * HS); l.eLm1 = take((size_t)n * HT);
+        const size_t setup_end = t;
         size_t A_size = t;
         t = A2; l.C = take(NN); A_size = t > A_size ? t : A_size;
         t = A1;
@@ -137,6 +136,11 @@ struct CgLap {
         l.Lm0 = take((size_t)n * P); l.gu1 = take((size_t)n * HS); l.Ls1 = take((size_t)n * HS); l.Lm1 = take((size_t)n * HT);
         l.Lgb = take(HS); l.Am = take((size_t)n * HS * P); l.Hk = take((size_t)n * HS * D);
         l.SQ = take((size_t)n * HT * D); l.Er = take((size_t)n * HS * D); l.Su2 = take((size_t)n * HS); l.Ls2 = take((size_t)n * HS);
+        A_size = t > A_size ? t : A_size;
+        // the early pair sums: behind everything the set-up, the Slater part AND the forward Laplacian use (the reverse sweep, which
+        // runs last, overlays them)
+        t = t > setup_end ? t : setup_end;
+        l.eLm0 = take((size_t)n * P); l.egu1 = take((size_t)n * HS); l.eLm1 = take((size_t)n * HT);
         A_size = t > A_size ? t : A_size;
         // ---- B
         t = 0;
@@ -224,7 +228,7 @@ struct CgLap {
     template <bool AL>
     static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                              const Mem<AL>& mem, const Lay& l, bool& early /* in: wanted; out: done */) {
+                              const Mem<AL>& mem, const Lay& l, bool& early /* in: wanted; out: done */, bool& have_C) {
         const int N = n * D;
         const CgFastLds& o = l.o;
         double* da = mem.a + l.da; double* x = mem.p + l.x;
@@ -250,8 +254,10 @@ struct CgLap {
         CG_STAMP_START(27)
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
         bool inverted = false, early_done = false;
+        bool early_C = false;
 #if defined(__HIP_DEVICE_COMPILE__)
         early = early && b.nthr >= 192;
+        early_C = l.C + N * N <= l.Jc;
         if (N <= 32 && n <= 16 && b.nthr >= 128 && N * N + 2 * n * n >= 128) {      // (the Jc + Dc slots are the 128-double scratch)
             // both inverses by wave-level Gauss-Jordan in registers, concurrently on two waves (no barriers, J and D intact)
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
@@ -266,16 +272,18 @@ struct CgLap {
                 // the other waves, meanwhile: what needs neither inverse -- the pair sums of the forward Laplacian and C = J J^T
                 const CgBlk b2{b.tid - 128, b.nthr - 128};
                 fwd_pair_sums(b2, th, n, L, mem.a + l.pt, mem.a + l.eLm1, mem.a + l.eLm0, mem.a + l.egu1);
-                const double* J = da + o.J; double* C = mem.a + l.C;
-                cg_gemm_wg(b2, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
-                           [&](int r, int c, double v) { C[r * N + c] = v; });
+                if (early_C) {                  // (only where C's slot stays clear of the inverses' scratch at Jc: small n D = 3 does not)
+                    const double* J = da + o.J; double* C = mem.a + l.C;
+                    cg_gemm_wg(b2, N, N, N, [&](int r, int k) { return J[r * N + k]; }, [&](int k, int c) { return J[c * N + k]; },
+                               [&](int r, int c, double v) { C[r * N + c] = v; });
+                }
             }
             b.sync();
             inverted = true;
             early_done = early;
         }
 #endif
-        early = early_done;
+        early = early_done; have_C = early_done && early_C;
 #if defined(__HIP_DEVICE_COMPILE__)
         if (!inverted && l.stage_lds && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
             // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
@@ -1046,11 +1054,12 @@ struct CgLap {
         const bool exact_phi = mode != 1;
         bool early = exact_phi;                      // (set-up: granted on the wave-inverse path with waves to spare)
         CG_STAMP_START(20)
-        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l, early);
+        bool have_C = false;
+        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l, early, have_C);
         CG_STAMP_END(20)
         double s_re, s_im, q_re = 0, q_im = 0;
         CG_STAMP_START(21)
-        slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im, early);      // grad <- J^T g
+        slater_part<AL>(b, n, mem, l, exact_phi, grad, s_re, s_im, have_C);      // grad <- J^T g
         b.sync();                                                        // the forward Laplacian's arrays overlay J and C
         CG_STAMP_END(21)
         CG_STAMP_START(23)
