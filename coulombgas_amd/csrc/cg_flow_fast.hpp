@@ -665,6 +665,129 @@ struct CgFast {
     }
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---------------------------------------------------------------------------------------
+    // Second-order jets (directional passes of the Laplacian), dense probe: the two pair loops whose work items are (particle, unit)
+    // used to recompute the Jet2 features of pair (i, j) in each of the 16 unit lanes (~150 instructions, 16-fold redundant).  As in
+    // primal_pairs_dpp: a DPP row (16 lanes) owns particle i, each lane computes the features of ONE pair (i, 16 c + lane) and the row
+    // walks j by row broadcasts (2 v_mov_dpp per double).  spsize = tpsize = 16.
+    // ---------------------------------------------------------------------------------------
+    template <int LANE>
+    static __device__ __forceinline__ Jet2 jet_row_bcast(const Jet2& v) { return Jet2(row_bcast<LANE>(v.v), row_bcast<LANE>(v.d), row_bcast<LANE>(v.dd)); }
+    struct JPF { Jet2 c2[D], s2[D], del, sr[D]; };        // sr = s2 / del (G pass); del (primal pass)
+    // features of the lane's own pair; ok = false, or i == j in the G-pass flavour: all-zero jets (contribute nothing)
+    template <bool GPASS>
+    static __device__ __forceinline__ void jet_own_pair(const Jet2* sh, const Jet2* ch, int i, int j, bool ok, JPF& f) {
+        Jet2 d2(0.0);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const Jet2 si = ok ? sh[i * D + a] : Jet2(0.0), ci = ok ? ch[i * D + a] : Jet2(1.0), sj = ok ? sh[j * D + a] : Jet2(1.0), cj = ok ? ch[j * D + a] : Jet2(0.0);
+            const Jet2 sn = si * cj - ci * sj, cs = ci * cj + si * sj;
+            f.s2[a] = 2.0 * (sn * cs); f.c2[a] = 1.0 - 2.0 * (sn * sn); d2 += sn * sn;
+        }
+        const bool diag = i == j, live = ok && !diag;
+        if (live) {
+            f.del = cg_sqrt(d2);
+            if (GPASS) { const Jet2 rd = cg_rcp(f.del);
+#pragma unroll
+                for (int a = 0; a < D; ++a) f.sr[a] = f.s2[a] * rd; }
+        } else {
+            f.del = Jet2(0.0);
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                f.sr[a] = Jet2(0.0);
+                if (GPASS || !ok) { f.s2[a] = Jet2(0.0); f.c2[a] = Jet2(0.0); }          // G pass: the l = k term is absent
+                else { f.s2[a] = Jet2(0.0); f.c2[a] = Jet2(1.0); }                        // primal: exact diagonal feature [1.., 0.., 0]
+            }
+        }
+    }
+    template <int JJ>
+    static __device__ __forceinline__ void jet_primal_step(const JPF& mine, const double (&wt)[P], double bt, int jbase, int n, int h, Jet2& acc, Jet2& raw) {
+        if constexpr (JJ < 16) {
+            if (jbase + JJ < n) {                                  // wave-uniform
+                Jet2 u(bt);
+                Jet2 fv(0.0);
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const Jet2 c2 = jet_row_bcast<JJ>(mine.c2[a]), s2 = jet_row_bcast<JJ>(mine.s2[a]);
+                    u += wt[a] * c2 + wt[D + a] * s2;
+                    if (h == a) fv = c2;
+                    if (h == D + a) fv = s2;
+                }
+                const Jet2 del = jet_row_bcast<JJ>(mine.del);
+                u += wt[2 * D] * del;
+                if (h == 2 * D) fv = del;
+                acc += cg_softplus(u);
+                raw += fv;
+                jet_primal_step<JJ + 1>(mine, wt, bt, jbase, n, h, acc, raw);
+            }
+        }
+    }
+    static __device__ __forceinline__ void primal_pairs_jet_dpp(const CgBlk& b, const double* th, int n, Jet2* lds, const CgFastLds& o) {
+        const Jet2 *sh = lds + o.sh, *ch = lds + o.ch;
+        Jet2 *m0 = lds + o.m0, *m1 = lds + o.m1;
+        const double rn = 1.0 / (double)n;
+        const int h = b.tid & 15;
+        double wt[P]; const double bt = th[o_t0b + h];
+#pragma unroll
+        for (int f = 0; f < P; ++f) wt[f] = th[o_t0w + f * HT + h];
+        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {      // whole waves stay together
+            const int i = (e0 + (b.tid & 63)) >> 4;
+            const bool rowok = i < n;
+            Jet2 acc(0.0), raw(0.0);
+            for (int jb = 0; jb < n; jb += 16) {
+                JPF mine; jet_own_pair<false>(sh, ch, rowok ? i : 0, jb + h < n ? jb + h : 0, rowok && jb + h < n, mine);
+                jet_primal_step<0>(mine, wt, bt, jb, n, h, acc, raw);
+            }
+            if (rowok) { m1[i * HT + h] = acc * rn; if (h < P) m0[i * P + h] = raw * rn; }
+        }
+    }
+    template <int JJ>
+    static __device__ __forceinline__ void jet_g_step(const JPF& mine, const Jet2* sg1, const Jet2& sgk, const double (&kc)[D], const double (&ksn)[D], double kd,
+                                                      int lbase, int n, int h, Jet2 (&acc)[D]) {
+        if constexpr (JJ < 16) {
+            if (lbase + JJ < n) {
+                const Jet2 sgl = sg1[(lbase + JJ) * HS + h];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) {
+                    const Jet2 s2 = jet_row_bcast<JJ>(mine.s2[bb]), c2 = jet_row_bcast<JJ>(mine.c2[bb]), sr = jet_row_bcast<JJ>(mine.sr[bb]);
+                    const Jet2 odd = kc[bb] * s2 + kd * sr;          // odd in r:  (-c1 w_c) s2 + (c2c w_d) s2 / del
+                    const Jet2 evn = ksn[bb] * c2;                   // even in r: (c1 w_s) c2
+                    acc[bb] += sgk * (odd + evn) - sgl * (evn - odd);
+                }
+                jet_g_step<JJ + 1>(mine, sg1, sgk, kc, ksn, kd, lbase, n, h, acc);
+            }
+        }
+    }
+    static __device__ __forceinline__ void g_pass_jet_dpp(const CgBlk& b, const double* th, int n, double L, Jet2* lds, const CgFastLds& o) {
+        const Jet2 *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1;
+        Jet2* G = lds + o.G;
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        const int h = b.tid & 15;
+        double kc[D], ksn[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) { kc[a] = -c1 * th[o_W0 + a * HS + h]; ksn[a] = c1 * th[o_W0 + (D + a) * HS + h]; }
+        const double kd = c2c * th[o_W0 + 2 * D * HS + h];
+        for (int e0 = (b.tid >> 6) << 6; e0 < n * 16; e0 += b.nthr) {
+            const int k = (e0 + (b.tid & 63)) >> 4;
+            const bool rowok = k < n;
+            const Jet2 sgk = rowok ? sg1[k * HS + h] : Jet2(0.0);
+            Jet2 acc[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) acc[a] = Jet2(0.0);
+            for (int lb = 0; lb < n; lb += 16) {
+                JPF mine; jet_own_pair<true>(sh, ch, rowok ? k : 0, lb + h < n ? lb + h : 0, rowok && lb + h < n, mine);
+                jet_g_step<0>(mine, sg1, sgk, kc, ksn, kd, lb, n, h, acc);
+            }
+            if (rowok) {
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) G[iG(k, h, bb)] = acc[bb] * (rn * rn);
+            }
+        }
+    }
+#endif
+
     // ---------------------------------------------------------------------------------------
     // primal pass: fills sh,ch,m0,s1,sg1,m1,gbar,cb,sg2,s2,z in LDS.
     // ---------------------------------------------------------------------------------------
@@ -694,6 +817,11 @@ struct CgFast {
 #endif
         // pair-primal: item (i,h)
         constexpr int HM = HT > P ? HT : P;          // lanes h < P also carry one raw-feature mean
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (CgIsJet<T>::value && HS == 16 && HT == 16) {
+            if (!pairs_done && hot < 0 && (b.nthr & 63) == 0) { primal_pairs_jet_dpp(b, th, n, (Jet2*)lds, o); pairs_done = true; }   // dense probe
+        }
+#endif
         if constexpr (CgIsJet<T>::value) {
             // Sparse tangent of a basis-direction pass: rows i != hot see one jet pair (j = hot) and n - 1 double pairs;
             // the hot row's n x HM (j, h) units are spread over the whole workgroup through a scratch in J's slot (dead
@@ -890,6 +1018,13 @@ struct CgFast {
             V[iV(i, a, g)] = v * rn;
         }
         // G pass: item (k,h)
+        bool g_done = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (CgIsJet<T>::value && HS == 16 && HT == 16) {
+            if ((b.nthr & 63) == 0) { g_pass_jet_dpp(b, th, n, L, (Jet2*)lds, o); g_done = true; }
+        }
+#endif
+        if (!g_done)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;
             double w_c[D], w_s[D];

@@ -378,73 +378,71 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
     unsigned used = 0;
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;          // rows beyond the matrix never pivot
-    for (int k = 0; k < N; ++k) {
-        const int buf = k & 1;
-        const bool mycol = act && k >= j0 && k < j0 + TC;
-        if (mycol) {                                  // best unused row of column k in this tile
-            const int jk = k - j0;
-            double best = -2.0; int bi = 0x7fffffff;
+    // columns in groups of TC so that the pivot column's index inside its owners' tiles is a compile-time constant (the dynamic
+    // version extracted it with TR x TC selects, twice per column, and tested every element against row p / column k)
+    for (int kc = 0; kc < N; kc += TC) {
+        const bool mycol = act && j0 == kc;
 #pragma unroll
-            for (int ii = 0; ii < TR; ++ii) {
-                double v = 0.0;
+        for (int jk = 0; jk < TC; ++jk) {
+            const int k = kc + jk;
+            if (k < N) {                                  // (workgroup-uniform)
+                const int buf = k & 1;
+                if (mycol) {                              // best unused row of column k in this tile
+                    double best = -2.0; int bi = 0x7fffffff;
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) v = jj == jk ? a[ii][jj] : v;
-                v = fabs(v);
-                const bool free_row = !((used >> ii) & 1u);
-                if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }     // (an all-NaN column still gets a pivot row)
-                if (free_row && v > best) { best = v; bi = i0 + ii; }
-            }
-            cv[tr] = best; ci[tr] = bi;
-        }
-        b.sync();
-        double best = cv[0]; int p = ci[0];
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const double v = fabs(a[ii][jk]);
+                        const bool free_row = !((used >> ii) & 1u);
+                        if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }     // (an all-NaN column still gets a pivot row)
+                        if (free_row && v > best) { best = v; bi = i0 + ii; }
+                    }
+                    cv[tr] = best; ci[tr] = bi;
+                }
+                b.sync();
+                double best = cv[0]; int p = ci[0];
 #pragma unroll 4
-        for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
-        const bool myrow = act && p >= i0 && p < i0 + TR;
-        if (myrow) {
-            const int ip = p - i0;
+                for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+                const bool myrow = act && p >= i0 && p < i0 + TR;
+                const int ip = p - i0;
+                if (myrow) {
 #pragma unroll
-            for (int jj = 0; jj < TC; ++jj) {
-                double v = 0.0;
+                    for (int jj = 0; jj < TC; ++jj) {
+                        double v = 0.0;
 #pragma unroll
-                for (int ii = 0; ii < TR; ++ii) v = ii == ip ? a[ii][jj] : v;
-                if (j0 + jj < N) rowb[buf * N + j0 + jj] = v;
-            }
-            used |= 1u << ip;
-        }
-        if (mycol) {
-            const int jk = k - j0;
+                        for (int ii = 0; ii < TR; ++ii) v = ii == ip ? a[ii][jj] : v;
+                        if (j0 + jj < N) rowb[buf * N + j0 + jj] = v;
+                        if (mycol && jj == jk) cv[16 + buf] = 1.0 / v;   // the owner of the pivot publishes its reciprocal
+                    }
+                    used |= 1u << ip;
+                }
+                if (mycol) {
 #pragma unroll
-            for (int ii = 0; ii < TR; ++ii) {
-                double v = 0.0;
+                    for (int ii = 0; ii < TR; ++ii) if (i0 + ii < N) colb[buf * N + i0 + ii] = a[ii][jk];
+                }
+                if (b.tid == 0) piv[k] = p;
+                b.sync();
+                const double rinv = cv[16 + buf];
+                double rj[TC], cI[TR];
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) v = jj == jk ? a[ii][jj] : v;
-                if (i0 + ii < N) colb[buf * N + i0 + ii] = v;
-            }
-        }
-        if (b.tid == 0) piv[k] = p;
-        if (myrow && mycol) {                         // the owner of the pivot publishes its reciprocal (one division per column, not one per thread)
-            double pv = 0.0;
+                for (int jj = 0; jj < TC; ++jj) rj[jj] = (j0 + jj < N ? rowb[buf * N + j0 + jj] : 0.0) * rinv;
 #pragma unroll
-            for (int ii = 0; ii < TR; ++ii)
+                for (int ii = 0; ii < TR; ++ii) cI[ii] = i0 + ii < N ? colb[buf * N + i0 + ii] : 0.0;
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) pv = (ii == p - i0 && jj == k - j0) ? a[ii][jj] : pv;
-            cv[16 + buf] = 1.0 / pv;
-        }
-        b.sync();
-        const double rinv = cv[16 + buf];
-        double rj[TC];
+                for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < TC; ++jj) rj[jj] = (j0 + jj < N ? rowb[buf * N + j0 + jj] : 0.0) * rinv;
+                    for (int jj = 0; jj < TC; ++jj) a[ii][jj] = fma(-cI[ii], rj[jj], a[ii][jj]);       // every element; row p and column k fixed below
+                if (mycol) {
 #pragma unroll
-        for (int ii = 0; ii < TR; ++ii) {
-            const double cI = i0 + ii < N ? colb[buf * N + i0 + ii] : 0.0;
-            const bool isp = i0 + ii == p;
+                    for (int ii = 0; ii < TR; ++ii) a[ii][jk] = -cI[ii] * rinv;
+                }
+                if (myrow) {
 #pragma unroll
-            for (int jj = 0; jj < TC; ++jj) {
-                const bool isk = j0 + jj == k;
-                const double upd = fma(-cI, rj[jj], a[ii][jj]);
-                a[ii][jj] = isp ? (isk ? rinv : rj[jj]) : (isk ? -cI * rinv : upd);
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const bool isp = ii == ip;
+#pragma unroll
+                        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = isp ? ((mycol && jj == jk) ? rinv : rj[jj]) : a[ii][jj];
+                    }
+                }
             }
         }
     }
@@ -467,7 +465,7 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
     const int tr = b.tid / tcn, tc = b.tid - tr * tcn;
     const bool act = b.tid < trn * tcn;
     const int i0 = tr * TR, j0 = tc * TC;
-    double* rowb = sc; double* colb = sc + 4 * N; double* cv = sc + 8 * N; int* ci = (int*)(cv + 16); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    double* rowb = sc; double* colb = sc + 4 * N; double* cv = sc + 8 * N; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
     double ar[TR][TC], ai[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
@@ -480,69 +478,77 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
     unsigned used = 0;
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;
-    for (int k = 0; k < N; ++k) {
-        const int buf = k & 1;
-        const bool mycol = act && k >= j0 && k < j0 + TC;
-        if (mycol) {
-            const int jk = k - j0;
-            double best = -2.0; int bi = 0x7fffffff;
+    for (int kc = 0; kc < N; kc += TC) {
+        const bool mycol = act && j0 == kc;
 #pragma unroll
-            for (int ii = 0; ii < TR; ++ii) {
-                double vr = 0.0, vi = 0.0;
+        for (int jk = 0; jk < TC; ++jk) {
+            const int k = kc + jk;
+            if (k < N) {
+                const int buf = k & 1;
+                if (mycol) {
+                    double best = -2.0; int bi = 0x7fffffff;
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) { vr = jj == jk ? ar[ii][jj] : vr; vi = jj == jk ? ai[ii][jj] : vi; }
-                const double v = vr * vr + vi * vi;
-                const bool free_row = !((used >> ii) & 1u);
-                if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }
-                if (free_row && v > best) { best = v; bi = i0 + ii; }
-            }
-            cv[tr] = best; ci[tr] = bi;
-        }
-        b.sync();
-        double best = cv[0]; int p = ci[0];
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const double v = ar[ii][jk] * ar[ii][jk] + ai[ii][jk] * ai[ii][jk];
+                        const bool free_row = !((used >> ii) & 1u);
+                        if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }
+                        if (free_row && v > best) { best = v; bi = i0 + ii; }
+                    }
+                    cv[tr] = best; ci[tr] = bi;
+                }
+                b.sync();
+                double best = cv[0]; int p = ci[0];
 #pragma unroll 4
-        for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
-        const bool myrow = act && p >= i0 && p < i0 + TR;
-        if (myrow) {
-            const int ip = p - i0;
+                for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+                const bool myrow = act && p >= i0 && p < i0 + TR;
+                const int ip = p - i0;
+                if (myrow) {
 #pragma unroll
-            for (int jj = 0; jj < TC; ++jj) {
-                double vr = 0.0, vi = 0.0;
+                    for (int jj = 0; jj < TC; ++jj) {
+                        double vr = 0.0, vi = 0.0;
 #pragma unroll
-                for (int ii = 0; ii < TR; ++ii) { vr = ii == ip ? ar[ii][jj] : vr; vi = ii == ip ? ai[ii][jj] : vi; }
-                if (j0 + jj < N) { rowb[2 * (buf * N + j0 + jj)] = vr; rowb[2 * (buf * N + j0 + jj) + 1] = vi; }
-            }
-            used |= 1u << ip;
-        }
-        if (mycol) {
-            const int jk = k - j0;
+                        for (int ii = 0; ii < TR; ++ii) { vr = ii == ip ? ar[ii][jj] : vr; vi = ii == ip ? ai[ii][jj] : vi; }
+                        if (j0 + jj < N) { rowb[2 * (buf * N + j0 + jj)] = vr; rowb[2 * (buf * N + j0 + jj) + 1] = vi; }
+                        if (mycol && jj == jk) { const CgCplx r = cinv({vr, vi}); cv[16 + 2 * buf] = r.re; cv[17 + 2 * buf] = r.im; }
+                    }
+                    used |= 1u << ip;
+                }
+                if (mycol) {
 #pragma unroll
-            for (int ii = 0; ii < TR; ++ii) {
-                double vr = 0.0, vi = 0.0;
+                    for (int ii = 0; ii < TR; ++ii) if (i0 + ii < N) { colb[2 * (buf * N + i0 + ii)] = ar[ii][jk]; colb[2 * (buf * N + i0 + ii) + 1] = ai[ii][jk]; }
+                }
+                if (b.tid == 0) piv[k] = p;
+                b.sync();
+                const CgCplx rinv = {cv[16 + 2 * buf], cv[17 + 2 * buf]};
+                CgCplx rj[TC], cI[TR];
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) { vr = jj == jk ? ar[ii][jj] : vr; vi = jj == jk ? ai[ii][jj] : vi; }
-                if (i0 + ii < N) { colb[2 * (buf * N + i0 + ii)] = vr; colb[2 * (buf * N + i0 + ii) + 1] = vi; }
-            }
-        }
-        if (b.tid == 0) piv[k] = p;
-        b.sync();
-        const CgCplx rinv = cinv({colb[2 * (buf * N + p)], colb[2 * (buf * N + p) + 1]});
-        CgCplx rj[TC];
+                for (int jj = 0; jj < TC; ++jj)
+                    rj[jj] = j0 + jj < N ? cmul({rowb[2 * (buf * N + j0 + jj)], rowb[2 * (buf * N + j0 + jj) + 1]}, rinv) : CgCplx{0.0, 0.0};
 #pragma unroll
-        for (int jj = 0; jj < TC; ++jj)
-            rj[jj] = j0 + jj < N ? cmul({rowb[2 * (buf * N + j0 + jj)], rowb[2 * (buf * N + j0 + jj) + 1]}, rinv) : CgCplx{0.0, 0.0};
+                for (int ii = 0; ii < TR; ++ii) cI[ii] = i0 + ii < N ? CgCplx{colb[2 * (buf * N + i0 + ii)], colb[2 * (buf * N + i0 + ii) + 1]} : CgCplx{0.0, 0.0};
 #pragma unroll
-        for (int ii = 0; ii < TR; ++ii) {
-            const CgCplx cI = i0 + ii < N ? CgCplx{colb[2 * (buf * N + i0 + ii)], colb[2 * (buf * N + i0 + ii) + 1]} : CgCplx{0.0, 0.0};
-            const bool isp = i0 + ii == p;
-            const CgCplx ck = cmul(cI, rinv);
+                for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < TC; ++jj) {
-                const bool isk = j0 + jj == k;
-                const CgCplx t = cmul(cI, rj[jj]);
-                const double ur = ar[ii][jj] - t.re, ui = ai[ii][jj] - t.im;
-                ar[ii][jj] = isp ? (isk ? rinv.re : rj[jj].re) : (isk ? -ck.re : ur);
-                ai[ii][jj] = isp ? (isk ? rinv.im : rj[jj].im) : (isk ? -ck.im : ui);
+                    for (int jj = 0; jj < TC; ++jj) {
+                        const CgCplx t = cmul(cI[ii], rj[jj]);
+                        ar[ii][jj] -= t.re; ai[ii][jj] -= t.im;
+                    }
+                if (mycol) {
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii) { const CgCplx ck = cmul(cI[ii], rinv); ar[ii][jk] = -ck.re; ai[ii][jk] = -ck.im; }
+                }
+                if (myrow) {
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const bool isp = ii == ip;
+#pragma unroll
+                        for (int jj = 0; jj < TC; ++jj) {
+                            const bool pk = mycol && jj == jk;
+                            ar[ii][jj] = isp ? (pk ? rinv.re : rj[jj].re) : ar[ii][jj];
+                            ai[ii][jj] = isp ? (pk ? rinv.im : rj[jj].im) : ai[ii][jj];
+                        }
+                    }
+                }
             }
         }
     }
