@@ -925,22 +925,26 @@ __device__ __forceinline__ void cg_wave_lu2_both(const double* A, int N, int lda
 #if defined(__HIP_DEVICE_COMPILE__)
 template <int NMAX>
 __device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int lda, double* Ainv, int ldi, double* scr) {
+    // IN-PLACE Gauss-Jordan (round 3): the slot of column k receives the inverse's column as soon as column k is eliminated, so a
+    // lane carries NMAX / 2 doubles instead of NMAX ([A | I]) and a step is NMAX / 2 multiply-adds and LDS words per lane instead of
+    // ~NMAX.  Rows never move (a finished pivot row stops being a candidate); with p_k the pivot row of column k the slots end as
+    //     A^-1[k][p_j] = S[p_k][j],   resolved while storing.
     constexpr int MH = NMAX / 2, MHP = (MH + 1) & ~1;
     const int lane = threadIdx.x & 63, r = lane >> 1, c = lane & 1;
-    double a[MH], bi[MH];
+    double a[MH];
 #pragma unroll
     for (int m = 0; m < MH; ++m) {
         const int j = 2 * m + c;
         a[m] = (r < N && j < N) ? A[r * lda + j] : 0.0;
-        bi[m] = (j == r) ? 1.0 : 0.0;
     }
     bool done = r >= N;
     unsigned long long donemask = N >= 32 ? 0ull : ~0ull << (2 * N);
     int myk = -1;
-    double* mineA = scr + c * MHP;
-    double* mineB = scr + 2 * MHP + c * MHP;
+    int pv[NMAX];                                        // pivot row of every column (wave-uniform)
+    double* mine = scr + c * MHP;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
+        pv[k] = 0;
         if (k < N) {
             const int ck = k & 1, mk = k >> 1;
             const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);
@@ -953,59 +957,59 @@ __device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int
                 p = mask ? (int)__builtin_ctzll(mask) : p;
                 piv = cg_readlane_f64(ak, p);
             }
+            pv[k] = p >> 1;
             const double rinv = cg_fast_rcp(piv);
             const bool isp = r == (p >> 1);
             const double l = isp ? 0.0 : ak * rinv;          // Jordan step: every other row, finished ones included
-            const int m0 = ck ? mk + 1 : mk;
             if (isp) {
 #pragma unroll
-                for (int m = m0; m < MH; ++m) mineA[m] = a[m];
-#pragma unroll
-                for (int m = 0; m < MH; ++m) mineB[m] = bi[m];
+                for (int m = 0; m < MH; ++m) mine[m] = a[m];
             }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int m = m0; m < MH; ++m) a[m] = fma(-l, mineA[m], a[m]);
-#pragma unroll
-            for (int m = 0; m < MH; ++m) bi[m] = fma(-l, mineB[m], bi[m]);
+            for (int m = 0; m < MH; ++m) a[m] = fma(-l, mine[m], a[m]);
             asm volatile("" ::: "memory");
-            if (isp) {                                       // the pivot row itself: scaled, it is row k of [I | A^-1] now
+            if (isp) {                                       // the pivot row itself: scaled
 #pragma unroll
-                for (int m = m0; m < MH; ++m) a[m] *= rinv;
-#pragma unroll
-                for (int m = 0; m < MH; ++m) bi[m] *= rinv;
+                for (int m = 0; m < MH; ++m) a[m] *= rinv;
                 myk = k;
             }
+            if (c == ck) a[mk] = isp ? rinv : -l;            // the slot of column k now holds the inverse's column
             done = done || isp;
             donemask |= 3ull << (p & ~1);
         }
     }
     if (myk >= 0) {
 #pragma unroll
-        for (int m = 0; m < MH; ++m) { const int j = 2 * m + c; if (j < N) Ainv[myk * ldi + j] = bi[m]; }
+        for (int m = 0; m < MH; ++m) {
+            const int j = 2 * m + c;
+            const int pj = c ? pv[2 * m + 1 < NMAX ? 2 * m + 1 : 0] : pv[2 * m];
+            if (j < N) Ainv[myk * ldi + pj] = a[m];
+        }
     }
 }
 
 template <int NMAX>
 __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, int lda, double* Ainv, int ldi, double* scr) {
+    // in-place Gauss-Jordan, as the real version: lane = 4 row + c holds the columns 4 m + c of its row
     constexpr int MQ = (NMAX + 3) / 4;
     const int lane = threadIdx.x & 63, r = lane >> 2, c = lane & 3;
-    double ar[MQ], ai[MQ], br[MQ], bim[MQ];
+    double ar[MQ], ai[MQ];
 #pragma unroll
     for (int m = 0; m < MQ; ++m) {
         const int j = 4 * m + c;
         const bool ok = r < N && j < N;
         ar[m] = ok ? A[2 * (r * lda + j)] : 0.0;
         ai[m] = ok ? A[2 * (r * lda + j) + 1] : 0.0;
-        br[m] = (j == r) ? 1.0 : 0.0; bim[m] = 0.0;
     }
     bool done = r >= N;
     unsigned long long donemask = N >= 16 ? 0ull : ~0ull << (4 * N);
     int myk = -1;
-    double* mineA = scr + 2 * c;                        // complex element j = 4 m + c at scr[2 j]
-    double* mineB = scr + 2 * (4 * MQ) + 2 * c;
+    int pv[4 * MQ];
+    double* mine = scr + 2 * c;                         // complex element j = 4 m + c at scr[2 j]
 #pragma unroll
-    for (int k = 0; k < NMAX; ++k) {
+    for (int k = 0; k < 4 * MQ; ++k) {
+        pv[k] = 0;
         if (k < N) {
             const int ck = k & 3, mk = k >> 2;
             double akr, aki;
@@ -1021,40 +1025,31 @@ __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, 
                 const unsigned long long mask = __ballot(key == mx && !done);
                 p = mask ? (int)__builtin_ctzll(mask) : p;
             }
+            pv[k] = p >> 2;
             const bool isp = r == (p >> 2);
             const CgCplx piv = {cg_readlane_f64(akr, p), cg_readlane_f64(aki, p)};
             const double rd = cg_fast_rcp(piv.re * piv.re + piv.im * piv.im);
             const CgCplx rinv = {piv.re * rd, -piv.im * rd};
             CgCplx l = cmul({akr, aki}, rinv);
             if (isp) { l.re = 0.0; l.im = 0.0; }
-            const int m0 = ck == 3 ? mk + 1 : mk;
             if (isp) {
 #pragma unroll
-                for (int m = m0; m < MQ; ++m) { mineA[8 * m] = ar[m]; mineA[8 * m + 1] = ai[m]; }
-#pragma unroll
-                for (int m = 0; m < MQ; ++m) { mineB[8 * m] = br[m]; mineB[8 * m + 1] = bim[m]; }
+                for (int m = 0; m < MQ; ++m) { mine[8 * m] = ar[m]; mine[8 * m + 1] = ai[m]; }
             }
             asm volatile("" ::: "memory");
 #pragma unroll
-            for (int m = m0; m < MQ; ++m) {
-                const double pr = mineA[8 * m], pi = mineA[8 * m + 1];
+            for (int m = 0; m < MQ; ++m) {
+                const double pr = mine[8 * m], pi = mine[8 * m + 1];
                 ar[m] = fma(-l.re, pr, fma(l.im, pi, ar[m]));
                 ai[m] = fma(-l.re, pi, fma(-l.im, pr, ai[m]));
             }
-#pragma unroll
-            for (int m = 0; m < MQ; ++m) {
-                const double pr = mineB[8 * m], pi = mineB[8 * m + 1];
-                br[m] = fma(-l.re, pr, fma(l.im, pi, br[m]));
-                bim[m] = fma(-l.re, pi, fma(-l.im, pr, bim[m]));
-            }
             asm volatile("" ::: "memory");
             if (isp) {
 #pragma unroll
-                for (int m = m0; m < MQ; ++m) { const CgCplx v = cmul({ar[m], ai[m]}, rinv); ar[m] = v.re; ai[m] = v.im; }
-#pragma unroll
-                for (int m = 0; m < MQ; ++m) { const CgCplx v = cmul({br[m], bim[m]}, rinv); br[m] = v.re; bim[m] = v.im; }
+                for (int m = 0; m < MQ; ++m) { const CgCplx v = cmul({ar[m], ai[m]}, rinv); ar[m] = v.re; ai[m] = v.im; }
                 myk = k;
             }
+            if (c == ck) { ar[mk] = isp ? rinv.re : -l.re; ai[mk] = isp ? rinv.im : -l.im; }
             done = done || isp;
             donemask |= 15ull << (p & ~3);
         }
@@ -1063,7 +1058,8 @@ __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, 
 #pragma unroll
         for (int m = 0; m < MQ; ++m) {
             const int j = 4 * m + c;
-            if (j < N) { Ainv[2 * (myk * ldi + j)] = br[m]; Ainv[2 * (myk * ldi + j) + 1] = bim[m]; }
+            const int pj = c == 0 ? pv[4 * m] : c == 1 ? pv[4 * m + 1] : c == 2 ? pv[4 * m + 2] : pv[4 * m + 3];
+            if (j < N) { Ainv[2 * (myk * ldi + pj)] = ar[m]; Ainv[2 * (myk * ldi + pj) + 1] = ai[m]; }
         }
     }
 }
