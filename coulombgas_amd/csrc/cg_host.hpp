@@ -177,6 +177,12 @@ static CgDev make_dev(const cg_ctx* c) {
     return m;
 }
 
+// launch-shape overrides for tuning runs (unset: the built-in choice)
+static inline int cg_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 template <class K>
 static int set_lds(cg_ctx* c, K kernel, size_t bytes) {
     if (bytes > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "workgroup needs %zu bytes of LDS (> 160 KiB): n too large for the LDS-resident path", bytes);
