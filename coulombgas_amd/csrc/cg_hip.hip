@@ -290,6 +290,9 @@ void cg_destroy(cg_ctx* c) {
     if (c->d_G) (void)hipFree(c->d_G);
     if (c->d_gk) (void)hipFree(c->d_gk);
     if (c->d_accept) (void)hipFree(c->d_accept);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);

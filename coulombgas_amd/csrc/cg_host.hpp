@@ -82,6 +82,8 @@ struct cg_ctx {
     CgVanModel van; double* d_van = nullptr; double* d_van_sp = nullptr; bool have_van = false;   // density-matrix Transformer (cg_van_*)
     double* d_van_scores = nullptr; size_t van_scores_cap = 0; int van_scores_B = 0;              // resident classical scores
     std::string err;
+    hipStream_t stream2 = nullptr;                     // look-ahead stream of the blocked Cholesky (bulk trailing updates)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
 };
 
 #define CG_FAIL(ctx, code, ...)                                         \
