@@ -986,7 +986,7 @@ def test_classical_fisher_and_blocked_cholesky_at_ragged_sizes():
         F = eng.fisher_real(S)
         ref = S.T @ S / B
         assert np.abs(F - ref).max() < 1e-13 * np.abs(ref).max() * np.sqrt(B) and np.array_equal(F, F.T), (B, P)
-    for P in (64, 65, 127, 333, 700, 1153):
+    for P in (64, 65, 127, 256, 257, 333, 512, 513, 700, 769, 1153):       # (256-column outer blocks: look-ahead from three of them on)
         S = rng.standard_normal((2 * P, P))
         M = S.T @ S / (2 * P) + 1e-3 * np.eye(P)
         Lg = eng.cholesky(M)
@@ -996,6 +996,12 @@ def test_classical_fisher_and_blocked_cholesky_at_ragged_sizes():
         xg = eng.spd_solve(M, rhs, 1e-3)
         xr = np.linalg.solve(M + 1e-3 * np.eye(P), rhs)
         assert np.abs(xg - xr).max() < 1e-10 * np.abs(xr).max(), P
+    # a non-positive pivot deep inside the matrix (fourth outer block, second 64-column step) is reported, not factored through
+    from coulombgas_amd._lib import CoulombGasError
+    d = np.ones(900); d[840] = -1.0
+    for fn in (lambda: eng.cholesky(np.diag(d)), lambda: eng.spd_solve(np.diag(d), np.ones(900))):
+        with pytest.raises(CoulombGasError, match="not positive definite"):
+            fn()
     eng.close()
 
 
