@@ -2,7 +2,8 @@
 # GPU box: everything profiles/ holds for one state of the tree (run at the end of a round):  tools/gpu_profiles.sh TAG -> gpurun_out/TAG/
 #   bench line (plain and under rocprofv3), kernel stats of the bench run, FETCH / WRITE / SQ counter passes of k_mcmc and the traffic
 #   file bench.py reads, the same for the derivative kernels at n = 13 / 29 / 57 (tools/gpu_baseline_derivs.sh), kernel stats of SR and
-#   hybrid epochs, bench lines + sampler stamps at n = 29 / 57.
+#   hybrid epochs, the damped solve at P = 5907 (kernel stats + a stretch of the two-stream timeline), bench lines + sampler stamps at
+#   n = 29 / 57.
 set -e
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
@@ -26,6 +27,11 @@ rocprofv3 --kernel-trace --stats -d $OUT/st_hyb -- python3 tools/epoch_breakdown
 python3 tools/profile_summary.py stats $OUT/st_hyb > $OUT/kernel_stats_hybrid_epoch_n13_B8192.csv
 for cfg in "13 8192" "29 2048" "57 512"; do set -- $cfg; python3 tools/epoch_breakdown.py $1 $2 > $OUT/epoch_breakdown_n$1.txt 2>&1; done
 echo "epochs done"
+python3 tools/solve_timing.py 333 1074 5907 > $OUT/solve_timing.txt 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/st_solve -- python3 tools/solve_timing.py 5907 > /dev/null 2> $OUT/st_solve.log
+python3 tools/profile_summary.py stats $OUT/st_solve > $OUT/kernel_stats_spd_solve_P5907.csv
+python3 tools/profile_summary.py timeline $OUT/st_solve chol 40 > $OUT/timeline_spd_solve_P5907.txt
+echo "solve done"
 python3 bench.py --n 29 --batch 2048 --Emax 25 --no-update-extras > $OUT/bench_n29.json 2> $OUT/bench_n29.err
 python3 bench.py --n 57 --batch 512 --Emax 49 --no-update-extras > $OUT/bench_n57.json 2> $OUT/bench_n57.err
 rocprofv3 --kernel-trace --stats -d $OUT/st_n29 -- python3 bench.py --n 29 --batch 2048 --Emax 25 --no-cpu-baseline --no-energy-check --no-update-extras > /dev/null 2> $OUT/st_n29.log
@@ -38,5 +44,5 @@ if [ -f coulombgas_amd/lib/diag/libcg_stamps.so ]; then
     [ "$1" = "13" ] && (COULOMBGAS_HIP_LIB=coulombgas_amd/lib/diag/libcg_stamps.so python3 tools/stamps_scores.py 13 8192 > $OUT/stamps_k_scores_n13.txt 2>&1 || true)
   done
 fi
-for d in $OUT/st_bench $OUT/st_sr $OUT/st_hyb $OUT/st_n29 $OUT/st_n57 $OUT/pmc_bench_*; do [ -d "$d" ] && rm -rf "$d"; done
+for d in $OUT/st_bench $OUT/st_solve $OUT/st_sr $OUT/st_hyb $OUT/st_n29 $OUT/st_n57 $OUT/pmc_bench_*; do [ -d "$d" ] && rm -rf "$d"; done
 ls $OUT

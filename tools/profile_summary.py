@@ -2,7 +2,9 @@
 """Export what the judge reads from a rocprofv3 output directory (its *_results.db): the per-kernel totals of a
 --kernel-trace --stats run as CSV, or the mean of every --pmc counter per kernel.
    python tools/profile_summary.py stats gpurun_out/<dir> > profiles/<name>.csv
-   python tools/profile_summary.py pmc   gpurun_out/<dir> [kernel-name-substring ...] > profiles/<name>.txt"""
+   python tools/profile_summary.py pmc   gpurun_out/<dir> [kernel-name-substring ...] > profiles/<name>.txt
+   python tools/profile_summary.py timeline gpurun_out/<dir> <kernel-name-substring> <count>   (the last <count> matching launches but 30:
+                                            stream, start, duration, grid -- what runs beside what)"""
 import sys, glob, sqlite3, collections
 
 mode, root = sys.argv[1], sys.argv[2]
@@ -12,6 +14,13 @@ if mode == "stats":
     print("kernel,calls,total_us,average_us,percent")
     for name, calls, total, avg, pct in c.execute("select * from top_kernels"):
         print('"%s",%d,%.3f,%.3f,%.4f' % (name.replace('"', "'"), calls, total, avg, pct))
+elif mode == "timeline":
+    sub, cnt = sys.argv[3], int(sys.argv[4])
+    rows = [r for r in c.execute("select name, start, end, stream_id, grid_x, grid_y from kernels order by start") if sub in r[0]]
+    sel = rows[-(cnt + 30):-30] if len(rows) > cnt + 30 else rows
+    t0 = sel[0][1]
+    for r in sel:
+        print("%-24s stream %s  start %9.1f us  duration %7.1f us  grid %s x %s" % (r[0].split("(")[0][:24], r[3], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[4], r[5]))
 else:
     want = sys.argv[3:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
