@@ -940,11 +940,11 @@ __device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int
     bool done = r >= N;
     unsigned long long donemask = N >= 32 ? 0ull : ~0ull << (2 * N);
     int myk = -1;
-    int pv[NMAX];                                        // pivot row of every column (wave-uniform)
+    int pv[MH];                                          // pivot row of the lane's own columns j = 2 m + c (registers: static indices only)
     double* mine = scr + c * MHP;
 #pragma unroll
     for (int k = 0; k < NMAX; ++k) {
-        pv[k] = 0;
+        if ((k & 1) == 0) pv[k >> 1] = 0;
         if (k < N) {
             const int ck = k & 1, mk = k >> 1;
             const double ak = ck ? cg_dpp_f64<0xF5>(a[mk]) : cg_dpp_f64<0xA0>(a[mk]);
@@ -957,7 +957,7 @@ __device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int
                 p = mask ? (int)__builtin_ctzll(mask) : p;
                 piv = cg_readlane_f64(ak, p);
             }
-            pv[k] = p >> 1;
+            if (c == ck) pv[mk] = p >> 1;
             const double rinv = cg_fast_rcp(piv);
             const bool isp = r == (p >> 1);
             const double l = isp ? 0.0 : ak * rinv;          // Jordan step: every other row, finished ones included
@@ -983,8 +983,7 @@ __device__ __forceinline__ void cg_wave_inverse_real(const double* A, int N, int
 #pragma unroll
         for (int m = 0; m < MH; ++m) {
             const int j = 2 * m + c;
-            const int pj = c ? pv[2 * m + 1 < NMAX ? 2 * m + 1 : 0] : pv[2 * m];
-            if (j < N) Ainv[myk * ldi + pj] = a[m];
+            if (j < N) Ainv[myk * ldi + pv[m]] = a[m];
         }
     }
 }
@@ -1005,11 +1004,11 @@ __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, 
     bool done = r >= N;
     unsigned long long donemask = N >= 16 ? 0ull : ~0ull << (4 * N);
     int myk = -1;
-    int pv[4 * MQ];
+    int pv[MQ];                                         // pivot row of the lane's own columns j = 4 m + c
     double* mine = scr + 2 * c;                         // complex element j = 4 m + c at scr[2 j]
 #pragma unroll
     for (int k = 0; k < 4 * MQ; ++k) {
-        pv[k] = 0;
+        if ((k & 3) == 0) pv[k >> 2] = 0;
         if (k < N) {
             const int ck = k & 3, mk = k >> 2;
             double akr, aki;
@@ -1025,7 +1024,7 @@ __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, 
                 const unsigned long long mask = __ballot(key == mx && !done);
                 p = mask ? (int)__builtin_ctzll(mask) : p;
             }
-            pv[k] = p >> 2;
+            if (c == ck) pv[mk] = p >> 2;
             const bool isp = r == (p >> 2);
             const CgCplx piv = {cg_readlane_f64(akr, p), cg_readlane_f64(aki, p)};
             const double rd = cg_fast_rcp(piv.re * piv.re + piv.im * piv.im);
@@ -1058,8 +1057,7 @@ __device__ __forceinline__ void cg_wave_inverse_complex(const double* A, int N, 
 #pragma unroll
         for (int m = 0; m < MQ; ++m) {
             const int j = 4 * m + c;
-            const int pj = c == 0 ? pv[4 * m] : c == 1 ? pv[4 * m + 1] : c == 2 ? pv[4 * m + 2] : pv[4 * m + 3];
-            if (j < N) { Ainv[2 * (myk * ldi + pj)] = ar[m]; Ainv[2 * (myk * ldi + pj) + 1] = ai[m]; }
+            if (j < N) { Ainv[2 * (myk * ldi + pv[m])] = ar[m]; Ainv[2 * (myk * ldi + pv[m]) + 1] = ai[m]; }
         }
     }
 }

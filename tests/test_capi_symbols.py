@@ -69,3 +69,40 @@ def test_product_never_imports_oracle_or_emulation():
     code = ("import sys; import coulombgas_amd; "
             "assert 'torch' not in sys.modules and not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)")
     subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_production_kernels_carry_no_register_spill_scratch(tmp_path):
+    """The kernels of the shipped configuration (d = 2, hs = ht = 16) in the built code objects: `.private_segment_fixed_size`
+    <= 64 B per lane -- the bound the round-2 review set for the derivative kernels after 972 / 1172 B.  (Read from the library's
+    gfx950 code-object metadata: no GPU needed.  A 208-byte pivot array slipped into all five derivative kernels once between two
+    profile collections; this is the guard.)"""
+    import shutil
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("ROCm's llvm-objdump / llvm-readelf not found")
+    from coulombgas_amd import _lib
+    from coulombgas_amd.build import build_hip
+    build_hip()
+    so = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.check_call([os.path.join(llvm, "llvm-objdump"), "--offloading", so], cwd=str(tmp_path), stdout=subprocess.DEVNULL)
+    seen = {}
+    for f in sorted(os.listdir(str(tmp_path))):
+        if "amdgcn" not in f:
+            continue
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / f)], capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s+\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s+\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name:
+                seen[name] = int(m.group(1))
+    want = ("k_grad_lap2ILi2ELi16ELi16E", "k_scoresILi2ELi16ELi16E", "k_param_vjpILi2ELi16ELi16E", "k_mcmcILi2ELi16ELi16ELi64ELi13E",
+            "k_mcmcILi2ELi16ELi16ELi256ELi29E", "k_mcmcILi2ELi16ELi16ELi512ELi57E", "k_chol_block", "k_chol_trsm", "k_chol_xinv", "k_chol_update", "k_fisher")
+    for w in want:
+        hits = {k: v for k, v in seen.items() if w in k}
+        assert hits, "kernel %s not found in the library" % w
+        for k, v in hits.items():
+            assert v <= 64, "%s: %d B of scratch per lane" % (k, v)
