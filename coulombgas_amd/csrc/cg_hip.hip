@@ -596,6 +596,17 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
           if (per_cu > best) { best = per_cu; waves = w; }
       } }
     if (waves == 0) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
+    // small batches of long sequences (n = 57, B = 512: the staged weights leave LDS for ONE wave per CU, two rounds of samples): without the
+    // staged copy (weights through L1 / L2) more waves fit a CU; taken when it saves >= 1.4x in rounds (8.5 -> 5.8 ms there; at n = 13,
+    // B = 8192 the staged weights win, 5.8 against 6.3 ms)
+    if (plds) {
+        int w0 = 1; while (w0 < 8 && (size_t)(w0 + 1) * wbytes <= 160 * 1024) ++w0;
+        int best0 = 0, wsel = 1;
+        for (int w = 1; w <= w0; ++w) { const int per_cu = w * (int)((160 * 1024) / (w * wbytes)); if (per_cu > best0 || (per_cu == best0 && w <= 2)) { best0 = per_cu; wsel = w; } }
+        const int per_cu1 = waves * (int)((160 * 1024) / (pbytes + waves * wbytes));
+        const int rounds1 = (B + c->cu_count * per_cu1 - 1) / (c->cu_count * per_cu1), rounds0 = (B + c->cu_count * best0 - 1) / (c->cu_count * best0);
+        if (rounds0 * 7 <= rounds1 * 5) { plds = 0; waves = wsel; }
+    }
     const size_t lds = (plds ? pbytes : 0) + waves * wbytes;
     if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van_scores_compute: one sample needs %zu bytes of LDS", wbytes);
     const int grid = std::min((B + waves - 1) / waves, c->cu_count * 4);
