@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) k_randn(double* __restrict__ out, size_t 
 }
 // Autoregressive Transformer density matrix (cg_van.hpp): one wave per sample, `waves` samples per workgroup.
 // LDS: [parameters (if plds)] [per-wave scratch: activations + key / value cache].
-template <bool SAMPLE>
+template <bool SAMPLE, bool SHIPPED>       // SHIPPED: model size 16, hidden 32, two layers, four heads at compile time
 __global__ void __launch_bounds__(256) k_van(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
                                              int* __restrict__ sidx, const double* __restrict__ unif, uint64_t seed, uint64_t offset,
                                              double* __restrict__ logp, int plds) {
@@ -135,8 +135,8 @@ __global__ void __launch_bounds__(256) k_van(CgVanModel m, const double* __restr
     }
     double* lw = scratch + (size_t)wave * m.wave_doubles;
     for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves) {
-        const double lp = cg_van_sequence<SAMPLE>(m, P, sp, sidx + (size_t)s * m.n, lw, unif ? unif + (size_t)s * m.n * m.M : nullptr,
-                                                  seed, offset + (uint64_t)s);
+        const double lp = SHIPPED ? cg_van_sequence<SAMPLE, 16, 32, 2, 4>(m, P, sp, sidx + (size_t)s * m.n, lw, unif ? unif + (size_t)s * m.n * m.M : nullptr, seed, offset + (uint64_t)s)
+                                  : cg_van_sequence<SAMPLE>(m, P, sp, sidx + (size_t)s * m.n, lw, unif ? unif + (size_t)s * m.n * m.M : nullptr, seed, offset + (uint64_t)s);
         if ((threadIdx.x & 63) == 0 && logp) logp[s] = lp;
     }
 }
@@ -157,6 +157,43 @@ __global__ void __launch_bounds__(512) k_van_grad(CgVanModel m, const double* __
     double* stash = stash_all + (size_t)(blockIdx.x * waves + wave) * (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
     for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves)
         cg_van_gradient(m, P, sp, sidx + (size_t)s * m.n, lw, stash, S + (size_t)s * m.total);
+}
+// the shipped model dimensions at compile time (model size 16, hidden 32, two layers, four heads), gradient row accumulated in HBM / L2
+__global__ void __launch_bounds__(512) k_van_grad_s(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
+                                                    const int* __restrict__ sidx, double* __restrict__ S, double* __restrict__ stash_all, int plds) {
+    extern __shared__ double van_lds[];
+    const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const double* P = Pg;
+    double* scratch = van_lds;
+    if (plds) {
+        for (int e = threadIdx.x; e < m.total; e += blockDim.x) van_lds[e] = Pg[e];
+        P = van_lds; scratch = van_lds + ((m.total + 1) & ~1);
+        __syncthreads();
+    }
+    double* lw = scratch + (size_t)wave * cg_van_grad_wave_doubles(m);
+    double* stash = stash_all + (size_t)(blockIdx.x * waves + wave) * (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
+    for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves)
+        cg_van_gradient_static<16, 32, 2, 4>(m, P, sp, sidx + (size_t)s * m.n, lw, stash, S + (size_t)s * m.total);
+}
+// the same with the gradient row accumulated in registers (CgVanAccReg): at most four waves per workgroup = one per SIMD, the shipped
+// model dimensions (model size 16, hidden 32, two layers), M <= 64 MR orbitals
+template <int MS, int HS, int NL, int MR>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_van_grad_reg(CgVanModel m, const double* __restrict__ Pg, const double* __restrict__ sp, int B,
+               const int* __restrict__ sidx, double* __restrict__ S, double* __restrict__ stash_all, int plds) {
+    extern __shared__ double van_lds[];
+    const int waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    const double* P = Pg;
+    double* scratch = van_lds;
+    if (plds) {
+        for (int e = threadIdx.x; e < m.total; e += blockDim.x) van_lds[e] = Pg[e];
+        P = van_lds; scratch = van_lds + ((m.total + 1) & ~1);
+        __syncthreads();
+    }
+    double* lw = scratch + (size_t)wave * cg_van_grad_wave_doubles(m);
+    double* stash = stash_all + (size_t)(blockIdx.x * waves + wave) * (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
+    for (int s = blockIdx.x * waves + wave; s < B; s += gridDim.x * waves)
+        cg_van_gradient_reg<MS, HS, NL, MR>(m, P, sp, sidx + (size_t)s * m.n, lw, stash, S + (size_t)s * m.total);
 }
 // out[slice][p] = sum_{b in slice} w[b] S[b][p] for a real (B x P) matrix (the classical theta-VJP from resident scores)
 __global__ void __launch_bounds__(256) k_gemv_t(const double* __restrict__ S, const double* __restrict__ w, int B, int P, int chunk,
@@ -523,15 +560,16 @@ static int van_launch(cg_ctx* c, bool sample, int B, int* sidx_dev, const double
     if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van: the key / value cache of one sample needs %zu bytes of LDS", wbytes);
     const int grid = std::min((B + waves - 1) / waves, c->cu_count * 8);
     int rc;
-    if (sample) {
-        if ((rc = set_lds(c, k_van<true>, lds))) return rc;
-        hipLaunchKernelGGL(k_van<true>, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
-                           sidx_dev, unif_dev, seed, offset, logp_dev, plds);
-    } else {
-        if ((rc = set_lds(c, k_van<false>, lds))) return rc;
-        hipLaunchKernelGGL(k_van<false>, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
-                           sidx_dev, unif_dev, seed, offset, logp_dev, plds);
-    }
+    // compile-time dimensions pay when a CU holds few waves (latency-bound: n = 57, B = 512: 1.29 -> 1.05 ms; n = 29, B = 2048: 1.22 -> 1.02);
+    // with every SIMD full (n = 13, B = 8192) the unrolled products cost more registers than they hide: 1.27 against 1.72 ms
+    const bool shipped = m.ms == 16 && m.hs == 32 && m.nl == 2 && m.nh == 4 && cg_env_int("CG_VAN_STATIC", B <= 16 * c->cu_count ? 1 : 0);
+#define CG_VAN_LAUNCH(S, H)                                                                                                              \
+    { if ((rc = set_lds(c, k_van<S, H>, lds))) return rc;                                                                                \
+      hipLaunchKernelGGL((k_van<S, H>), dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B, \
+                         sidx_dev, unif_dev, seed, offset, logp_dev, plds); }
+    if (sample) { if (shipped) CG_VAN_LAUNCH(true, true) else CG_VAN_LAUNCH(true, false) }
+    else { if (shipped) CG_VAN_LAUNCH(false, true) else CG_VAN_LAUNCH(false, false) }
+#undef CG_VAN_LAUNCH
     return CG_OK;
 }
 int cg_van_log_prob(cg_ctx* c, const int32_t* state_idx, int B, double* logp) {
@@ -607,14 +645,33 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
         const int rounds1 = (B + c->cu_count * per_cu1 - 1) / (c->cu_count * per_cu1), rounds0 = (B + c->cu_count * best0 - 1) / (c->cu_count * best0);
         if (rounds0 * 7 <= rounds1 * 5) { plds = 0; waves = wsel; }
     }
+    if (cg_env_int("CG_VAN_GRAD_REG", 1) == 2 && waves > 4) waves = 4;
     const size_t lds = (plds ? pbytes : 0) + waves * wbytes;
     if (lds > 160 * 1024) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_van_scores_compute: one sample needs %zu bytes of LDS", wbytes);
     const int grid = std::min((B + waves - 1) / waves, c->cu_count * 4);
     const size_t stash_per_wave = (size_t)(m.n > 1 ? m.n - 1 : 1) * cg_van_token_stash(m);
     if ((rc = ensure_ws(c, sizeof(double) * stash_per_wave * (size_t)grid * waves))) return rc;
-    if ((rc = set_lds(c, k_van_grad, lds))) return rc;
-    hipLaunchKernelGGL(k_van_grad, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
-                       (const int*)as.dev, c->d_van_scores, (double*)c->ws, plds);
+    const int regmode = cg_env_int("CG_VAN_GRAD_REG", 1);
+    const bool shipped = m.ms == 16 && m.hs == 32 && m.nl == 2 && m.nh == 4;
+    const bool reg_ok = regmode > 0 && waves <= 4 && shipped && m.dim * m.ms <= 64 && m.M <= 256;
+#define CG_VAN_REG_LAUNCH(MR)                                                                                                         \
+    { if ((rc = set_lds(c, k_van_grad_reg<16, 32, 2, MR>, lds))) return rc;                                                           \
+      hipLaunchKernelGGL((k_van_grad_reg<16, 32, 2, MR>), dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van,   \
+                         (const double*)c->d_van_sp, B, (const int*)as.dev, c->d_van_scores, (double*)c->ws, plds); }
+    if (reg_ok && m.M <= 64) CG_VAN_REG_LAUNCH(1)
+    else if (reg_ok && m.M <= 128) CG_VAN_REG_LAUNCH(2)
+    else if (reg_ok && m.M <= 192) CG_VAN_REG_LAUNCH(3)
+    else if (reg_ok) CG_VAN_REG_LAUNCH(4)
+    else if (shipped && regmode >= 0) {
+        if ((rc = set_lds(c, k_van_grad_s, lds))) return rc;
+        hipLaunchKernelGGL(k_van_grad_s, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
+                           (const int*)as.dev, c->d_van_scores, (double*)c->ws, plds);
+    } else {
+        if ((rc = set_lds(c, k_van_grad, lds))) return rc;
+        hipLaunchKernelGGL(k_van_grad, dim3(grid), dim3(64 * waves), lds, c->stream, m, (const double*)c->d_van, (const double*)c->d_van_sp, B,
+                           (const int*)as.dev, c->d_van_scores, (double*)c->ws, plds);
+    }
+#undef CG_VAN_REG_LAUNCH
     c->van_scores_B = B;
     return finish(c);
 }

@@ -42,24 +42,41 @@ CG_HD int cg_van_grad_wave_doubles(const CgVanModel& m) { return (12 * m.ms + 3 
 CG_HD int cg_van_token_stash(const CgVanModel& m) { return 2 * m.ms + m.nl * (4 * m.ms + m.hs + m.nh * m.n); }
 
 #if defined(__HIPCC__)
+// wave-wide sum / maximum, the result in every lane: DPP row scans (row_shr 1, 2, 4, 8: lane 15 of a row ends with the row's total) and
+// four readlanes, fixed order ((r0 + r1) + (r2 + r3)).  The xor-butterfly of __shfl_xor goes through the LDS crossbar (ds_bpermute, six
+// dependent round trips of two dwords): ~700 cycles against ~150, and a token pass has ~100 of these reductions.
+template <int CTRL>
+__device__ __forceinline__ double cg_van_dpp(double v, double fill) {
+    const long long u = __double_as_longlong(v), f = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)f, (int)u, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(f >> 32), (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double cg_van_readlane(double v, int l) {
+    const long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double cg_wsum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += cg_van_dpp<0x111>(v, 0.0); v += cg_van_dpp<0x112>(v, 0.0); v += cg_van_dpp<0x114>(v, 0.0); v += cg_van_dpp<0x118>(v, 0.0);
+    return (cg_van_readlane(v, 15) + cg_van_readlane(v, 31)) + (cg_van_readlane(v, 47) + cg_van_readlane(v, 63));
 }
 __device__ __forceinline__ double cg_wmax(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    v = fmax(v, cg_van_dpp<0x111>(v, -INFINITY)); v = fmax(v, cg_van_dpp<0x112>(v, -INFINITY));
+    v = fmax(v, cg_van_dpp<0x114>(v, -INFINITY)); v = fmax(v, cg_van_dpp<0x118>(v, -INFINITY));
+    return fmax(fmax(cg_van_readlane(v, 15), cg_van_readlane(v, 31)), fmax(cg_van_readlane(v, 47), cg_van_readlane(v, 63)));
 }
 
 // One sample on one wave.  SAMPLE: draws state_idx[0..n) (written to sidx) with Gumbel-max noise from `unif` (n x M, parity
 // mode) or the Philox stream (seed, stream); otherwise reads sidx.  Returns log p(state_idx) in every lane.
-template <bool SAMPLE>
-__device__ __forceinline__ double cg_van_sequence(const CgVanModel& m, const double* P, const double* __restrict__ sp,
+// MS / HS / NL / NH > 0: the model dimensions at compile time (the 16- and 32-term products unroll, their weight loads overlap)
+template <bool SAMPLE, int MS = 0, int HS = 0, int NL = 0, int NH = 0>
+__device__ __forceinline__ double cg_van_sequence(const CgVanModel& m_, const double* P, const double* __restrict__ sp,
                                                   int* __restrict__ sidx, double* lw, const double* __restrict__ unif,
                                                   uint64_t seed, uint64_t stream) {
     const int lane = threadIdx.x & 63;
+    CgVanModel m = m_;
+    if (MS > 0) { m.ms = MS; m.hs = HS; m.nl = NL; m.nh = NH; m.ks = MS / NH; }
     const int ms = m.ms, hs = m.hs, M = m.M, n = m.n, ks = m.ks;
     double* h = lw; double* q = h + ms; double* att = q + ms; double* h1 = att + ms; double* th = h1 + ms; double* mid = th + ms;
     double* kc = mid + hs; double* vc = kc + (size_t)m.nl * n * ms;      // [layer][position][feature]
@@ -200,11 +217,174 @@ __device__ __forceinline__ void cg_van_outer(double* __restrict__ G, const doubl
 __device__ __forceinline__ void cg_van_vadd(double* __restrict__ G, const double* d, int nout, int lane) {
     for (int j = lane; j < nout; j += 64) G[j] += d[j];
 }
+// Where the gradient row of a sample is accumulated.  CgVanAccGlobal: in the row itself (HBM / L2), any model.  CgVanAccReg: in
+// registers with the same entry <-> lane mapping and the same order of operations (so the same bits), stored once at the end -- for
+// workgroups of at most four waves (one wave per SIMD: 512 registers per lane); the reverse pass of a token was ~120 dependent global
+// read-modify-writes per lane.
+struct CgVanAccGlobal {
+    static constexpr int NL_STATIC = 0, MS_STATIC = 0, HS_STATIC = 0, NH_STATIC = 0;
+    double* G; const CgVanModel& m; int lane;
+    __device__ __forceinline__ CgVanAccGlobal(double* G_, const CgVanModel& m_, int lane_) : G(G_), m(m_), lane(lane_) {
+        for (int e = lane; e < m.total; e += 64) G[e] = 0.0;
+    }
+    __device__ __forceinline__ void x1(int r, int j, double v) { (void)r; G[m.o_x1 + j] = v; }
+    __device__ __forceinline__ void out(int r, int j, const double* th, double dy) {
+        (void)r;
+        G[m.o_ob + j] += dy;
+        for (int i0 = 0; i0 < m.ms; i0 += 8) {                               // eight read-modify-writes in flight
+            double g[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[u] = i0 + u < m.ms ? G[m.o_ow + (i0 + u) * m.M + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u < m.ms) G[m.o_ow + (i0 + u) * m.M + j] = fma(th[i0 + u], dy, g[u]);
+        }
+    }
+    // slot: 0 query, 1 key, 2 value, 3 attention output (bias + ms x ms weights each), 4 mlp linear (hs, ms x hs), 5 mlp linear_1 (ms, hs x ms)
+    __device__ __forceinline__ double* base(int l, int slot) const {
+        const int blk = m.ms + m.ms * m.ms;
+        return G + m.o_l[l] + (slot <= 4 ? slot * blk : 4 * blk + m.hs + m.ms * m.hs);
+    }
+    __device__ __forceinline__ void layer(int l, int slot, const double* a, const double* d, int nin, int nout) {
+        double* b = base(l, slot);
+        cg_van_vadd(b, d, nout, lane); cg_van_outer(b + nout, a, d, nin, nout, lane);
+    }
+    __device__ __forceinline__ void emb(const double* __restrict__ spc, const double* dpre) {
+        cg_van_vadd(G + m.o_eb, dpre, m.ms, lane);
+        for (int e = lane; e < m.dim * m.ms; e += 64) { const int c = e / m.ms, j = e - c * m.ms; G[m.o_ew + e] = fma(spc[c], dpre[j], G[m.o_ew + e]); }
+    }
+    __device__ __forceinline__ void finish() {}
+};
+// the same accumulation in the row itself, with the model dimensions known at compile time (any number of waves per workgroup)
+template <int MS, int HS, int NL, int NH>
+struct CgVanAccGlobalS : CgVanAccGlobal {
+    static constexpr int NL_STATIC = NL, MS_STATIC = MS, HS_STATIC = HS, NH_STATIC = NH;
+    __device__ __forceinline__ CgVanAccGlobalS(double* G_, const CgVanModel& m_, int lane_) : CgVanAccGlobal(G_, m_, lane_) {}
+};
+template <int MS, int HS, int NL, int MR>
+struct CgVanAccReg {
+    static constexpr int NL_STATIC = NL, MS_STATIC = MS, HS_STATIC = HS, NH_STATIC = 4;      // (the shipped models: four heads)
+    static constexpr int KW = MS * MS / 64, KH = MS * HS / 64;
+    static_assert(MS * MS % 64 == 0 && MS * HS % 64 == 0 && MS <= 64 && HS <= 64, "register accumulators: whole 64-lane sweeps");
+    double* G; const CgVanModel& m; int lane;
+    double ow[MR][MS], ob[MR], xh[MR];
+    double w[NL][4][KW], w1[NL][KH], w2[NL][KH], bs[NL][6], eb, ew;
+    __device__ __forceinline__ CgVanAccReg(double* G_, const CgVanModel& m_, int lane_) : G(G_), m(m_), lane(lane_) {
+#pragma unroll
+        for (int r = 0; r < MR; ++r) { ob[r] = 0.0; xh[r] = 0.0;
+#pragma unroll
+            for (int i = 0; i < MS; ++i) ow[r][i] = 0.0; }
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < KW; ++k) w[l][q][k] = 0.0;
+#pragma unroll
+            for (int k = 0; k < KH; ++k) { w1[l][k] = 0.0; w2[l][k] = 0.0; }
+#pragma unroll
+            for (int q = 0; q < 6; ++q) bs[l][q] = 0.0;
+        }
+        eb = 0.0; ew = 0.0;
+    }
+    __device__ __forceinline__ void x1(int r, int j, double v) {
+        (void)j;
+#pragma unroll
+        for (int rr = 0; rr < MR; ++rr) if (rr == r) xh[rr] = v;
+    }
+    __device__ __forceinline__ void out(int r, int j, const double* th, double dy) {
+        (void)j;
+#pragma unroll
+        for (int rr = 0; rr < MR; ++rr)
+            if (rr == r) {
+                ob[rr] += dy;
+#pragma unroll
+                for (int i = 0; i < MS; ++i) ow[rr][i] = fma(th[i], dy, ow[rr][i]);
+            }
+    }
+    template <int CNT, int NOUT>
+    __device__ __forceinline__ void outer(double (&acc)[CNT], const double* a, const double* d) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) { const int e = lane + 64 * k, i = e / NOUT, j = e - i * NOUT; acc[k] = fma(a[i], d[j], acc[k]); }
+    }
+    // (l and slot are compile-time constants after the unrolled layer loop)
+    __device__ __forceinline__ void layer(int l, int slot, const double* a, const double* d, int nin, int nout) {
+        (void)nin;
+#pragma unroll
+        for (int ll = 0; ll < NL; ++ll)
+            if (ll == l) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) if (q == slot && lane < nout) bs[ll][q] += d[lane];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q == slot) outer<KW, MS>(w[ll][q], a, d);
+                if (slot == 4) outer<KH, HS>(w1[ll], a, d);
+                if (slot == 5) outer<KH, MS>(w2[ll], a, d);
+            }
+    }
+    __device__ __forceinline__ void emb(const double* __restrict__ spc, const double* dpre) {
+        if (lane < MS) eb += dpre[lane];
+        if (lane < m.dim * MS) { const int c = lane / MS, j = lane - c * MS; ew = fma(spc[c], dpre[j], ew); }
+    }
+    __device__ __forceinline__ void finish() {
+        const int M = m.M, blk = MS + MS * MS;
+#pragma unroll
+        for (int r = 0; r < MR; ++r) {
+            const int j = lane + 64 * r;
+            if (j < M) {
+                G[m.o_x1 + j] = xh[r]; G[m.o_ob + j] = ob[r];
+#pragma unroll
+                for (int i = 0; i < MS; ++i) G[m.o_ow + i * M + j] = ow[r][i];
+            }
+        }
+        if (lane < MS) G[m.o_eb + lane] = eb;
+        if (lane < m.dim * MS) G[m.o_ew + lane] = ew;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            double* Gl = G + m.o_l[l];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (lane < MS) Gl[q * blk + lane] = bs[l][q];
+#pragma unroll
+                for (int k = 0; k < KW; ++k) Gl[q * blk + MS + lane + 64 * k] = w[l][q][k];
+            }
+            if (lane < HS) Gl[4 * blk + lane] = bs[l][4];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) Gl[4 * blk + HS + lane + 64 * k] = w1[l][k];
+            if (lane < MS) Gl[4 * blk + HS + MS * HS + lane] = bs[l][5];
+#pragma unroll
+            for (int k = 0; k < KH; ++k) Gl[4 * blk + HS + MS * HS + MS + lane + 64 * k] = w2[l][k];
+        }
+    }
+};
+template <class ACC>
+__device__ __forceinline__ void cg_van_gradient_t(const CgVanModel& m, const double* P, const double* __restrict__ sp,
+                                                  const int* __restrict__ sidx, double* lw, double* __restrict__ stash, ACC& acc);
 __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const double* P, const double* __restrict__ sp,
                                                 const int* __restrict__ sidx, double* lw, double* __restrict__ stash,
                                                 double* __restrict__ G) {
+    CgVanAccGlobal acc(G, m, (int)(threadIdx.x & 63));
+    cg_van_gradient_t(m, P, sp, sidx, lw, stash, acc);
+}
+template <int MS, int HS, int NL, int NH>
+__device__ __forceinline__ void cg_van_gradient_static(const CgVanModel& m, const double* P, const double* __restrict__ sp,
+                                                       const int* __restrict__ sidx, double* lw, double* __restrict__ stash,
+                                                       double* __restrict__ G) {
+    CgVanAccGlobalS<MS, HS, NL, NH> acc(G, m, (int)(threadIdx.x & 63));
+    cg_van_gradient_t(m, P, sp, sidx, lw, stash, acc);
+}
+template <int MS, int HS, int NL, int MR>
+__device__ __forceinline__ void cg_van_gradient_reg(const CgVanModel& m, const double* P, const double* __restrict__ sp,
+                                                    const int* __restrict__ sidx, double* lw, double* __restrict__ stash,
+                                                    double* __restrict__ G) {
+    CgVanAccReg<MS, HS, NL, MR> acc(G, m, (int)(threadIdx.x & 63));
+    cg_van_gradient_t(m, P, sp, sidx, lw, stash, acc);
+}
+template <class ACC>
+__device__ __forceinline__ void cg_van_gradient_t(const CgVanModel& m, const double* P, const double* __restrict__ sp,
+                                                  const int* __restrict__ sidx, double* lw, double* __restrict__ stash, ACC& acc) {
     const int lane = threadIdx.x & 63;
-    const int ms = m.ms, hs = m.hs, M = m.M, n = m.n, ks = m.ks, nl = m.nl, nh = m.nh;
+    // (compile-time model dimensions in the register variant: the 16- and 32-term products below unroll, their weight loads overlap)
+    const int ms = ACC::MS_STATIC > 0 ? ACC::MS_STATIC : m.ms, hs = ACC::HS_STATIC > 0 ? ACC::HS_STATIC : m.hs, M = m.M, n = m.n;
+    const int nl = ACC::NL_STATIC > 0 ? ACC::NL_STATIC : m.nl, nh = ACC::NH_STATIC > 0 ? ACC::NH_STATIC : m.nh, ks = ms / nh;
     const int TS = cg_van_token_stash(m), LS = 4 * ms + hs + nh * n;       // stash per token / per layer inside it
     double* h = lw; double* q = h + ms; double* att = q + ms; double* h1 = att + ms; double* th = h1 + ms; double* mid = th + ms;
     double* dh = mid + hs; double* dh1 = dh + ms; double* dov = dh1 + ms; double* dq = dov + ms; double* dkt = dq + ms; double* dvt = dkt + ms;
@@ -212,7 +392,6 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
     double* kc = dyb + hs; double* vc = kc + (size_t)nl * n * ms;
     double* dkc = vc + (size_t)nl * n * ms; double* dvc = dkc + (size_t)nl * n * ms;
     const double rsk = 1.0 / sqrt((double)ks);
-    for (int e = lane; e < m.total; e += 64) G[e] = 0.0;
     for (int e = lane; e < 2 * nl * n * ms; e += 64) dkc[e] = 0.0;                 // dkc and dvc are contiguous
     // ---- forward over the tokens 0 .. n-2, stashing what the reverse pass needs
     for (int t = 0; t + 1 < n; ++t) {
@@ -295,7 +474,7 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
         for (int r = 0; r < 4; ++r) z += (lg[r] > -INFINITY) ? exp(lg[r] - mx) : 0.0;
         z = cg_wsum(z);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int j = lane + 64 * r; if (j < M && j <= hi) G[m.o_x1 + j] = (j == s0 ? 1.0 : 0.0) - exp(lg[r] - mx) / z; }
+        for (int r = 0; r < 4; ++r) { const int j = lane + 64 * r; if (j < M && j <= hi) acc.x1(r, j, (j == s0 ? 1.0 : 0.0) - exp(lg[r] - mx) / z); }
     }
     // ---- reverse pass
     for (int t = n - 2; t >= 0; --t) {
@@ -321,16 +500,7 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
         for (int r = 0; r < 4; ++r) {
             const int j = lane + 64 * r;
             dy[r] = (lg[r] > -INFINITY) ? (j == nxt ? 1.0 : 0.0) - exp(lg[r] - mx) / z : 0.0;
-            if (j < M && dy[r] != 0.0) {
-                G[m.o_ob + j] += dy[r];
-                for (int i0 = 0; i0 < ms; i0 += 8) {                               // eight read-modify-writes in flight
-                    double g[8];
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) g[u] = i0 + u < ms ? G[m.o_ow + (i0 + u) * M + j] : 0.0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) if (i0 + u < ms) G[m.o_ow + (i0 + u) * M + j] = fma(th[i0 + u], dy[r], g[u]);
-                }
-            }
+            if (j < M && dy[r] != 0.0) acc.out(r, j, th, dy[r]);
         }
         for (int i = 0; i < ms; ++i) {                                             // dh = (Wout dy) (1 - th^2)
             double a = 0.0;
@@ -340,9 +510,10 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
             if (lane == i) dh[i] = a * (1.0 - th[i] * th[i]);
         }
         asm volatile("" ::: "memory");
-        for (int l = nl - 1; l >= 0; --l) {
+#pragma unroll
+        for (int li = 0; li < (ACC::NL_STATIC > 0 ? ACC::NL_STATIC : nl); ++li) {
+            const int l = (ACC::NL_STATIC > 0 ? ACC::NL_STATIC : nl) - 1 - li;
             const double* Lp = P + m.o_l[l];
-            double* Gl = G + m.o_l[l];
             const int blk = ms + ms * ms;
             const double* sl = st + 2 * ms + (size_t)l * LS;
             if (lane < ms) { hin[lane] = sl[lane]; q[lane] = sl[ms + lane]; att[lane] = sl[2 * ms + lane]; h1[lane] = sl[3 * ms + lane]; }
@@ -350,16 +521,15 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
             asm volatile("" ::: "memory");
             const double* b1 = Lp + 4 * blk; const double* w1 = b1 + hs;
             const double* b2 = w1 + ms * hs; const double* w2 = b2 + ms;
-            double* Gb1 = Gl + 4 * blk; double* Gw1 = Gb1 + hs; double* Gb2 = Gw1 + ms * hs; double* Gw2 = Gb2 + ms;
             // DenseBlock: h = h1 + W2^T tanh(W1^T h1 + b1) + b2
-            cg_van_vadd(Gb2, dh, ms, lane); cg_van_outer(Gw2, mid, dh, hs, ms, lane);
+            acc.layer(l, 5, mid, dh, hs, ms);
             for (int i = lane; i < hs; i += 64) {
                 double a = 0.0;
                 for (int j = 0; j < ms; ++j) a = fma(w2[i * ms + j], dh[j], a);
                 dpre[i] = a * (1.0 - mid[i] * mid[i]);
             }
             asm volatile("" ::: "memory");
-            cg_van_vadd(Gb1, dpre, hs, lane); cg_van_outer(Gw1, h1, dpre, ms, hs, lane);
+            acc.layer(l, 4, h1, dpre, ms, hs);
             if (lane < ms) {
                 double a = dh[lane];
                 for (int i = 0; i < hs; ++i) a = fma(w1[lane * hs + i], dpre[i], a);
@@ -368,8 +538,7 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
             asm volatile("" ::: "memory");
             // attention output linear
             const double* ow = Lp + 3 * blk + ms;
-            double* Gob = Gl + 3 * blk; double* Gow = Gob + ms;
-            cg_van_vadd(Gob, dh1, ms, lane); cg_van_outer(Gow, att, dh1, ms, ms, lane);
+            acc.layer(l, 3, att, dh1, ms, ms);
             if (lane < ms) {
                 double a = 0.0;
                 for (int j = 0; j < ms; ++j) a = fma(ow[lane * ms + j], dh1[j], a);
@@ -399,9 +568,9 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
             if (lane < ms) { dkt[lane] = dkl[(size_t)t * ms + lane]; dvt[lane] = dvl[(size_t)t * ms + lane]; }
             asm volatile("" ::: "memory");
             // query / key / value linears of token t
-            cg_van_vadd(Gl, dq, ms, lane); cg_van_outer(Gl + ms, hin, dq, ms, ms, lane);
-            cg_van_vadd(Gl + blk, dkt, ms, lane); cg_van_outer(Gl + blk + ms, hin, dkt, ms, ms, lane);
-            cg_van_vadd(Gl + 2 * blk, dvt, ms, lane); cg_van_outer(Gl + 2 * blk + ms, hin, dvt, ms, ms, lane);
+            acc.layer(l, 0, hin, dq, ms, ms);
+            acc.layer(l, 1, hin, dkt, ms, ms);
+            acc.layer(l, 2, hin, dvt, ms, ms);
             if (lane < ms) {
                 const double* wq = Lp + ms; const double* wk = Lp + blk + ms; const double* wv = Lp + 2 * blk + ms;
                 double a = dh1[lane];
@@ -415,9 +584,9 @@ __device__ __forceinline__ void cg_van_gradient(const CgVanModel& m, const doubl
         // embedding
         if (lane < ms) { const double h0 = st[lane]; dpre[lane] = dh[lane] * (1.0 - h0 * h0); }
         asm volatile("" ::: "memory");
-        cg_van_vadd(G + m.o_eb, dpre, ms, lane);
-        for (int e = lane; e < m.dim * ms; e += 64) { const int c = e / ms, j = e - c * ms; G[m.o_ew + e] = fma(sp[(size_t)cur * m.dim + c], dpre[j], G[m.o_ew + e]); }
+        acc.emb(sp + (size_t)cur * m.dim, dpre);
         asm volatile("" ::: "memory");
     }
+    acc.finish();
 }
 #endif
