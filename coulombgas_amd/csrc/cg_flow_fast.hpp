@@ -182,8 +182,9 @@ struct CgFast {
     template <int LANE>
     static __device__ __forceinline__ double row_bcast(double v) {
         const long long u = __double_as_longlong(v);
-        const int lo = __builtin_amdgcn_update_dpp(0, (int)u, 0x150 + LANE, 0xf, 0xf, false);
-        const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x150 + LANE, 0xf, 0xf, false);
+        // (bound_ctrl set: every lane has a source, and the destination needs no zero-initialising move -- two instructions fewer per broadcast)
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)u, 0x150 + LANE, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), 0x150 + LANE, 0xf, 0xf, true);
         return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
     }
     struct PF6 { double c2[D], s2[D], del, rdel; };

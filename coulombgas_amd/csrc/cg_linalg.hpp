@@ -654,8 +654,8 @@ __device__ __forceinline__ void cg_fast_sqrt_rsqrt(double x, double& sq, double&
 template <int CTRL>
 __device__ __forceinline__ double cg_dpp_f64(double v) {
     const long long u = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, 0xf, 0xf, true);      // (quad_perm controls: every lane has a source;
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, 0xf, 0xf, true); //  bound_ctrl spares the zero-initialised destination)
     return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 

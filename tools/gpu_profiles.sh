@@ -26,6 +26,10 @@ python3 tools/profile_summary.py stats $OUT/st_sr > $OUT/kernel_stats_sr_epoch_n
 rocprofv3 --kernel-trace --stats -d $OUT/st_hyb -- python3 tools/epoch_breakdown.py 13 8192 --van > $OUT/hybrid_epoch_breakdown.txt 2> $OUT/st_hyb.log
 python3 tools/profile_summary.py stats $OUT/st_hyb > $OUT/kernel_stats_hybrid_epoch_n13_B8192.csv
 for cfg in "13 8192" "29 2048" "57 512"; do set -- $cfg; python3 tools/epoch_breakdown.py $1 $2 > $OUT/epoch_breakdown_n$1.txt 2>&1; done
+( echo "finite-temperature epochs (both parameter sets trained) at the per-GPU shapes of BASELINE configs 4 / 5 (tools/epoch_breakdown.py N B --van)"
+  for cfg in "29 2048" "57 512"; do set -- $cfg; echo; echo "== n=$1 B=$2"; python3 tools/epoch_breakdown.py $1 $2 --van 2>&1 | tail -n 8; done ) > $OUT/hybrid_epoch_breakdown_n29_n57.txt
+for cfg in "13 8192" "29 2048" "57 512"; do set -- $cfg; python3 tools/van_timing.py $1 $2 >> $OUT/van_timing.txt 2>&1; done
+python3 tools/fisher_timing.py > $OUT/fisher_timing.txt 2>&1
 echo "epochs done"
 python3 tools/solve_timing.py 333 1074 5907 > $OUT/solve_timing.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/st_solve -- python3 tools/solve_timing.py 5907 > /dev/null 2> $OUT/st_solve.log
