@@ -156,3 +156,30 @@ def test_shipped_n57_transformer_against_torch_autograd():
         gref = ravel_pytree({m: {l: tp[m][l].grad.numpy() for l in tp[m]} for m in tp})[0]
         assert np.abs(S[b] - gref).max() < 1e-11 * scale, (b, np.abs(S[b] - gref).max() / scale)
     eng.close()
+
+
+@pytest.mark.parametrize("n,Emax,fixture", [(13, 25, "pretrained_van_n13.npz"), (57, 49, "shipped_n57_rs10_van.npz")])
+def test_transformer_score_kernel_variants_agree_bit_for_bit(n, Emax, fixture, monkeypatch):
+    """k_van_grad (runtime model dimensions, gradient row accumulated in HBM), k_van_grad_s (compile-time dimensions) and
+    k_van_grad_reg (compile-time dimensions, gradient row in registers, <= 4 waves per workgroup) keep the entry <-> lane mapping and
+    the order of operations of the first: the per-sample scores are the same bits.  (CG_VAN_GRAD_REG: -1 generic, 0 static, 2 registers.)"""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    z = np.load(os.path.join(GOLDEN_DIR, fixture))
+    pv = {}
+    for k in z.files:
+        if "|" in k:
+            m, l = k.split("|"); pv.setdefault(m, {})[l] = z[k]
+    sp = orbitals(2, Emax)
+    eng = Engine(n, 2, 2, 16, 16, box_length(n, 2), sp)
+    van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=eng)
+    s_d = sampler(pv, 3, 96)
+    out = {}
+    for mode in ("-1", "0", "2"):
+        monkeypatch.setenv("CG_VAN_GRAD_REG", mode)
+        s_d.version += 1                                   # (defeat the engine's cache of resident scores)
+        out[mode] = np.array(log_prob.grad(pv, s_d))
+    assert np.isfinite(out["-1"]).all() and np.abs(out["-1"]).max() > 0
+    assert np.array_equal(out["-1"], out["0"]) and np.array_equal(out["-1"], out["2"])
+    eng.close()
