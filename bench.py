@@ -196,6 +196,22 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
     out["epoch_ms"] = float(ep[len(ep) // 2])
     out["epoch"] = "median wall time of epochs 3-5 of coulombgas_amd.train: batch %d, mc_steps %d, Hutchinson-split, SR damping 1e-3" % (B_epoch or B, mc_steps)
     out["last_row"] = rows[-1]
+    # finite-temperature epochs (main.py:152-164, 277-307 mirror): the autoregressive Transformer density matrix of the shipped runs
+    # (2 layers, model size 16, 4 heads, hidden 32; random-initialised) sampled, differentiated and trained on the device beside the flow:
+    # sampling + k_van, observables, both gradients, both Fisher matrices (P_van x P_van classical), both damped solves
+    try:
+        van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+        pv0 = van.init(5, sp[:n])
+        sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0])
+        marks2 = [time.perf_counter()]
+        cg.train(flow, p0, sp, n, dim, L, rs=10.0, beta=1 / (4 * 0.15), batch=B_epoch or B, epochs=5, sampler=sampler, log_prob=log_prob,
+                 params_van=pv0, sr=(1e-3, 1e-3), mc_therm=1, mc_steps=mc_steps, seed=4, log=lambda row: marks2.append(time.perf_counter()))
+        ep2 = sorted(np.diff(marks2)[2:] * 1e3)
+        out["hybrid_epoch_ms"] = float(ep2[len(ep2) // 2])
+        out["hybrid_epoch"] = ("median wall time of epochs 3-5 with the density-matrix Transformer trained too: P_van = %d parameters, "
+                               "classical Fisher matrix + second damped solve on the device" % lib().cg_van_num_params(sp.shape[0], 2, 16, 4, 32, dim))
+    except Exception as e:                                   # noqa: BLE001 -- a reporting extra must not lose the metric line
+        out["hybrid_epoch_ms"] = None; out["hybrid_epoch"] = "failed: %r" % (e,)
     out["seconds"] = time.perf_counter() - t0
     return out
 
