@@ -1206,7 +1206,9 @@ struct CgFast {
                 slater_matrix(b, lds + o.z, spk, sidx, n, lds + o.Dm, true);
                 CG_STAMP(12)                           // (diagnostic builds, this branch: 12 = Slater matrix, 13 = both LUs)
                 double lr;
-                cg_blocked_lu_dual(b, lds + o.J, n * D, n * D, lds + o.Dm, n, n, res, lr, la, ar);
+                // second generation (rows never move, GEMM-only helpers) wherever its 16-byte row accesses are aligned: every D = 2 system
+                if (((n * D) & 1) == 0 && n >= 8) cg_blocked_lu_dual2(b, lds + o.J, n * D, n * D, lds + o.Dm, n, n, res, lr, la, ar);
+                else cg_blocked_lu_dual(b, lds + o.J, n * D, n * D, lds + o.Dm, n, n, res, lr, la, ar);
                 half_logdetJ = 0.5 * lr;
                 CG_STAMP(13)
                 CG_STAMP(14)
@@ -1248,7 +1250,7 @@ static CG_HD CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, 
     if (alias && !small) {
         // large n: everything but z and the LU scratch is dead after the Jacobian assembly; kept contiguous so that the
         // Slater matrix fits over it (n = 57: 6626 doubles against 2 n^2 = 6498) and is factored WHILE J is factored.
-        o.z = take(n * D); o.perm = take(116);           // CG_LU_DUAL_DOUBLES: flags + every pivot of both LUs
+        o.z = take(n * D); o.perm = take(128);           // CG_LU_DUAL_DOUBLES: flags, pivots and live-tile masks of both LUs
         dead0 = t;
         o.sh = take(n * D); o.ch = take(n * D); o.sg1 = take(n * HS); o.sg2 = take(n * HS);
         o.wt = take(HT * (P + 1) + HS * D);

@@ -1295,6 +1295,7 @@ struct CgLuPanelReal {
             a0[j] = (r0 < N && (FULL || j < kb)) ? A[r0 * lda + k0 + j] : 0.0;
             a1[j] = (r1 < N && (FULL || j < kb)) ? A[r1 * lda + k0 + j] : 0.0;
         }
+        CG_STAMP(21)
         if (sk0 >= 0) {
             const bool two = N > k0 + 64;                                 // any second row of a lane (wave-uniform)
             if (FULL && skb == PW && (lda & 1) == 0) {                // full panels: unconditional, vector LDS reads
@@ -1337,6 +1338,7 @@ struct CgLuPanelReal {
                 }
             }
         }
+        CG_STAMP(22)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             if (FULL || j < kb) {
@@ -1385,6 +1387,7 @@ struct CgLuPanelReal {
                 }
             }
         }
+        CG_STAMP(23)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             if (FULL || j < kb) {
@@ -1393,6 +1396,7 @@ struct CgLuPanelReal {
             } else piv[j] = k0 + j;
             lrow[j] = a0[j];
         }
+        CG_STAMP_END(24)
     }
     // column() for the pivot chain: L11 and the pivots of the (full) panel come from the registers factor_keep() left them in
     static __device__ __forceinline__ void column_reg(double* A, int lda, int k0, const double (&lrow)[CG_LU_PW], const int (&piv)[CG_LU_PW],
@@ -1546,6 +1550,7 @@ struct CgLuPanelCplx {
             ar_[j] = ok ? A[2 * (r0 * lda + k0 + j)] : 0.0;
             ai_[j] = ok ? A[2 * (r0 * lda + k0 + j) + 1] : 0.0;
         }
+        CG_STAMP(26)
         if (sk0 >= 0) {                                                   // strip update by the full panel (sk0, PW)
             typedef double d2_t __attribute__((ext_vector_type(2)));
             const d2_t* pl = (const d2_t*)(A + 2 * ((r0 < N ? r0 : N - 1) * lda + sk0));
@@ -1565,6 +1570,7 @@ struct CgLuPanelCplx {
                 }
             }
         }
+        CG_STAMP(27)
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
             if (FULL || j < kb) {
@@ -1611,9 +1617,11 @@ struct CgLuPanelCplx {
                 }
             }
         }
+        CG_STAMP(28)
 #pragma unroll
         for (int j = 0; j < PW; ++j)
             if ((FULL || j < kb) && r0 < N) { A[2 * (r0 * lda + k0 + j)] = ar_[j]; A[2 * (r0 * lda + k0 + j) + 1] = ai_[j]; }
+        CG_STAMP_END(29)
     }
     static __device__ __forceinline__ void column(double* A, int lda, int k0, int kb, const int* pv, int c) {
         constexpr int PW = CG_LU_PW;
@@ -1746,12 +1754,19 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, dou
 //   dependency would give wrong numbers, never a hung GPU).  The arithmetic on each matrix is that of the sequential drivers
 //   in the same order: bitwise identical results.
 // res: CG_LU_DUAL_DOUBLES doubles of LDS.
-#define CG_LU_DUAL_DOUBLES 116
+#define CG_LU_DUAL_DOUBLES 128
 __device__ __forceinline__ int cg_flag_load(const int* f) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 __device__ __forceinline__ void cg_flag_store(int* f, int v, int lane) {
     if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// publication by the wave that wrote the data: LDS executes one wave's accesses in order, so a plain store issued after the data
+// stores becomes visible after them -- no s_waitcnt before it (the release store above drains the wave's LDS queue first)
+__device__ __forceinline__ void cg_flag_post(int* f, int v, int lane) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void cg_flag_wait(const int* f, int need) {
     for (int spin = 0; spin < (1 << 22) && cg_flag_load(f) < need; ++spin) __builtin_amdgcn_s_sleep(1);
@@ -1781,8 +1796,10 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
                 cg_flag_wait(app_r + ((k + 1) >> 1), k);
                 CG_STAMP_END(18)
             }
+            CG_STAMP_START(20)
             if (k >= 0) CgLuPanelReal::column_reg(A, lda, k0, lrow, piv, m0 + lane, lane < nb);
             asm volatile("" ::: "memory");                 // (LDS executes one wave's accesses in order)
+            CG_STAMP(20)
             CgLuPanelReal::factor_keep(A, N, lda, m0, nb, lane, pivr + m0, prod, k >= 0 ? k0 : -1, PW, lrow, piv);
             cg_flag_store(pub_r, k + 2, lane);
         }
@@ -1793,9 +1810,13 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
         CgCplx pm = {1.0, 0.0}; int pe = 0;
         for (int k = -1; k + 1 < npc; ++k) {
             const int k0 = k * PW, m0 = k0 + PW, nb = n - m0 < PW ? n - m0 : PW;
+            CG_STAMP_START(30)
             if (k > 0) cg_flag_wait(app_c + ((k + 1) >> 1), k);
+            CG_STAMP_END(30)
+            CG_STAMP_START(25)
             if (k >= 0 && lane < nb) CgLuPanelCplx::column(C, ldc, k0, PW, pivc + k0, m0 + lane);
             asm volatile("" ::: "memory");
+            CG_STAMP(25)
             CgLuPanelCplx::factor(C, n, ldc, m0, nb, lane, pivc + m0, pm, pe, k >= 0 ? k0 : -1);
             cg_flag_store(pub_c, k + 2, lane);
         }
@@ -1847,6 +1868,492 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
                 }
             }
             cg_flag_store(app_r + pick, tq + 1, lane);
+            CG_STAMP_END(19)
+        }
+    }
+    b.sync();
+    logabs_real = res[0]; logabs_c = res[1]; arg_c = res[2];
+    b.sync();
+}
+
+// ---- second generation of the concurrent pair (round 4): rows never move, helpers are pure GEMMs -----------------------------
+// What bounded cg_blocked_lu_dual was its two chain waves (profiles/r04a_lu_bench_*): per 8-column panel the real chain spent
+// 3.2 k cycles in the column steps and 7.6 k around them (U12 of its next columns by a readlane triangular solve, the strip
+// update out of LDS, the L panel stored and re-read in the shifted lane <-> row map, waiting for a helper), the helpers spent
+// half of every task in the 28-term triangular solve of their U12 block on 16 lanes.  Here
+//   * lane <-> row is FIXED (lane l owns rows l and l + 64) and rows are never exchanged: the pivot of a column is the natural
+//     row (row k if unused, else the first unused one) unless some unused row is more than 4x larger, then the largest (the
+//     threshold rule of the first generation); `used` rows keep multiplier 0 and drop out by themselves.  No exchange code,
+//     no deferred exchanges in the helpers, the multipliers stay in the registers they were formed in.
+//   * while a panel is factored the chain also carries E = -L21 L11^-1 (the column steps replayed on the identity: 28 terms,
+//     independent of the pivot chain, they fill its latency slots).  With E the Schur update needs no U12 at all:
+//         A22 - L21 (L11^-1 A12) = A22 + E A12[pivot rows, raw]
+//     so (1) the chain updates its NEXT eight columns in registers as a plain rank-8 update with broadcast pivot-row entries
+//     (64 independent terms per row instead of a triangular solve + strip), (2) E is what is published, and a helper task is
+//     a pure MFMA GEMM whose B operand is gathered by pivot index -- no triangular solve, no exchanges.
+//   * a row tile whose 16 rows have all served as pivots is skipped by the helpers (`live` mask per panel).
+// Flags / task scheme as in the first generation.  res: CG_LU_DUAL_DOUBLES doubles of LDS, 16-byte aligned.
+struct CgLu2 {
+    static constexpr int PW = CG_LU_PW;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    // int offsets inside the flag area
+    static constexpr int O_PUB_R = 0, O_PUB_C = 1, O_CLAIM = 2, O_APP = 14, O_PIVR = 32, O_PIVC = 160, O_LIVE_R = 224, O_LIVE_C = 240;
+
+    // per-lane select by a wave-uniform lane mask (the mask IS the condition register of the select)
+    static __device__ __forceinline__ int seli(unsigned long long mask, int v) {
+        int r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(mask)); return r;
+    }
+    static __device__ __forceinline__ double sel(unsigned long long mask, double v) {
+        const unsigned long long u = __double_as_longlong(v);
+        const int lo = seli(mask, (int)(unsigned)u), hi = seli(mask, (int)(unsigned)(u >> 32));
+        return __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+    }
+    static __device__ __forceinline__ int hi_abs(double v) { return (int)((unsigned)((unsigned long long)__double_as_longlong(v) >> 32) & 0x7fffffffu); }
+    // row tiles (16 rows) that still hold a live row: bit t of the result (l0: rows 0..63, l1: rows 64..127)
+    static __device__ __forceinline__ int live_tiles(unsigned long long l0, unsigned long long l1) {
+        int m = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((l0 >> (16 * t)) & 0xffffull) m |= 1 << t;
+            if ((l1 >> (16 * t)) & 0xffffull) m |= 16 << t;
+        }
+        return m;
+    }
+
+    // ---------------------------------------------------------------- real chain (one wave) ----------------------------------
+    // S = 1: N <= 64 (one row per lane), S = 2: N <= 128 (register slot s of lane l holds row l + 64 (s ^ swapped_l): a lane's
+    // two rows trade slots when the pivot turns up in the slot the panel code does not read -- rare, and lane-local).
+    // Rows that have served as pivot are not masked in the arithmetic: they compute garbage that nothing reads (the magnitude
+    // keys, E at publication and the pivot broadcasts only ever look at live rows).
+    template <int S>
+    struct Real {
+        double p[S][PW], e[S][PW];
+        unsigned long long live[2], swm;                                   // wave-uniform: live register positions per slot; lanes whose rows are swapped
+        int prow[PW], pl[PW];                                              // pivot rows / lanes of the current panel (wave-uniform)
+        double pm;
+    };
+    // column steps of one panel: pivots in slot SP (BOTH: the other slot takes part as well)
+    template <int S, int SP, bool BOTH, bool FULL>
+    static __device__ __forceinline__ void steps_real(Real<S>& st, int k0, int kb, int lane, CgScaledProd& prod) {
+        constexpr int S0 = BOTH ? 0 : SP, S1 = BOTH ? S : SP + 1;
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (FULL || j < kb) {
+                // natural row of the column in its natural place, alive, and no live entry more than ~4x larger (high words)?
+                int cl = (k0 + j) & 63;
+                int key[S];
+#pragma unroll
+                for (int s = S0; s < S1; ++s) key[s] = seli(st.live[s], hi_abs(st.p[s][j]));
+                const int kmx = (BOTH && S == 2) ? max(key[0], key[S - 1]) : key[SP];
+                const bool nat = ((st.live[SP] & ~st.swm) >> cl) & 1ull;
+                const int akk = __builtin_amdgcn_readlane(key[SP], cl);
+                if (!nat || __ballot((unsigned)kmx > (unsigned)akk + 0x00200000u)) {
+                    // rare: the largest live entry; a pivot in the other slot is brought over by a lane-local exchange
+                    unsigned kk = ((st.live[SP] >> lane) & 1ull) ? (unsigned)hi_abs(st.p[SP][j]) + 1u : 0u;
+                    int sl = SP;
+                    if (BOTH && S == 2) {
+                        const unsigned ko = ((st.live[1 - SP] >> lane) & 1ull) ? (unsigned)hi_abs(st.p[1 - SP][j]) + 1u : 0u;
+                        if (ko > kk) { kk = ko; sl = 1 - SP; }
+                    }
+                    const unsigned mx = cg_wave_max_u32(kk);
+                    cl = (int)__builtin_ctzll(__ballot(kk == mx));
+                    if (BOTH && S == 2) {
+                        if (__builtin_amdgcn_readlane(sl, cl) != SP) {
+                            const bool me = lane == cl;
+#pragma unroll
+                            for (int c = 0; c < PW; ++c) {
+                                const double t0 = st.p[0][c], t1 = st.p[S - 1][c], u0 = st.e[0][c], u1 = st.e[S - 1][c];
+                                st.p[0][c] = me ? t1 : t0; st.p[S - 1][c] = me ? t0 : t1;
+                                st.e[0][c] = me ? u1 : u0; st.e[S - 1][c] = me ? u0 : u1;
+                            }
+                            const unsigned long long bit = 1ull << cl, b0 = st.live[0] & bit, b1 = st.live[1] & bit;
+                            st.live[0] = (st.live[0] & ~bit) | b1; st.live[1] = (st.live[1] & ~bit) | b0;
+                            st.swm ^= bit;
+                        }
+                    }
+                }
+                st.pl[j] = cl;
+                st.prow[j] = S == 2 ? cl + 64 * (SP ^ (int)((st.swm >> cl) & 1ull)) : cl;
+                st.live[SP] &= ~(1ull << cl);
+                double rp[PW];
+#pragma unroll
+                for (int jj = j; jj < PW; ++jj) rp[jj] = cg_readlane_f64(st.p[SP][jj], cl);
+                st.pm *= rp[j];
+                if ((j & 3) == 3 || (!FULL && j + 1 == kb)) { prod.mul(st.pm); st.pm = 1.0; }
+                const double rinv = cg_fast_rcp1(rp[j]);
+                double u[PW];
+#pragma unroll
+                for (int c = 0; c < j; ++c) u[c] = cg_readlane_f64(st.e[SP][c], cl);
+#pragma unroll
+                for (int s = S0; s < S1; ++s) {
+                    const double l = st.p[s][j] * rinv;
+                    st.p[s][j] = l;
+#pragma unroll
+                    for (int jj = j + 1; jj < PW; ++jj) st.p[s][jj] = fma(-l, rp[jj], st.p[s][jj]);
+                    // E = -L21 L11^-1: the same row operations on the identity columns (off the pivot chain)
+#pragma unroll
+                    for (int c = 0; c < j; ++c) st.e[s][c] = fma(-l, u[c], st.e[s][c]);
+                    st.e[s][j] = -l;
+                }
+            } else {
+                st.pl[j] = 0; st.prow[j] = 0;
+#pragma unroll
+                for (int s = S0; s < S1; ++s) st.e[s][j] = 0.0;
+            }
+        }
+    }
+    // E published, the next eight columns fetched (once every older panel has reached their block) and updated in registers
+    template <int S, int SP, bool BOTH>
+    static __device__ __forceinline__ void next_real(Real<S>& st, double* A, int N, int lda, int k, int lane, int* fl) {
+        constexpr int S0 = BOTH ? 0 : SP, S1 = BOTH ? S : SP + 1;
+        const int k0 = k * PW, m0 = k0 + PW;
+        int row[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) row[s] = S == 2 ? lane + 64 * (s ^ (int)((st.swm >> lane) & 1ull)) : lane;
+#pragma unroll
+        for (int s = S0; s < S1; ++s) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) st.e[s][c] = sel(st.live[s], st.e[s][c]);
+            if (row[s] < N) {
+                d2_t* q = (d2_t*)(A + row[s] * lda + k0);
+#pragma unroll
+                for (int c = 0; c < PW / 2; ++c) q[c] = d2_t{st.e[s][2 * c], st.e[s][2 * c + 1]};
+            }
+        }
+        if (!BOTH && S == 2) {                                             // the slot that takes no part holds used rows only: E = 0 there
+            if (row[1 - SP] < N) {
+                d2_t* q = (d2_t*)(A + row[1 - SP] * lda + k0);
+#pragma unroll
+                for (int c = 0; c < PW / 2; ++c) q[c] = d2_t{0.0, 0.0};
+            }
+        }
+        if (lane == 0) {
+            i4_t* q = (i4_t*)(fl + O_PIVR + k0);
+            q[0] = i4_t{st.prow[0], st.prow[1], st.prow[2], st.prow[3]};
+            q[1] = i4_t{st.prow[4], st.prow[5], st.prow[6], st.prow[7]};
+            const unsigned long long l0 = (st.live[0] & ~st.swm) | (st.live[1] & st.swm), l1 = (st.live[1] & ~st.swm) | (st.live[0] & st.swm);
+            fl[O_LIVE_R + k] = live_tiles(l0, l1);
+        }
+        cg_flag_post(fl + O_PUB_R, k + 1, lane);
+        CG_STAMP(21)
+        if (k > 0) cg_flag_wait(fl + O_APP + ((k + 1) >> 1), k);
+        CG_STAMP(22)
+        double b[S][PW];
+#pragma unroll
+        for (int s = S0; s < S1; ++s) {
+            const d2_t* q = (const d2_t*)(A + (row[s] < N ? row[s] : N - 1) * lda + m0);
+#pragma unroll
+            for (int c = 0; c < PW / 2; ++c) { const d2_t v = q[c]; b[s][2 * c] = v[0]; b[s][2 * c + 1] = v[1]; }   // (columns >= N of the last panel: never used)
+        }
+        // p = b + E A12, A12 = the pivot rows' entries of the new columns as they stand in LDS (wave-uniform addresses: broadcast reads)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const d2_t* q = (const d2_t*)(A + st.prow[j] * lda + m0);
+            double u[PW];
+#pragma unroll
+            for (int c = 0; c < PW / 2; ++c) { const d2_t v = q[c]; u[2 * c] = v[0]; u[2 * c + 1] = v[1]; }
+#pragma unroll
+            for (int s = S0; s < S1; ++s)
+#pragma unroll
+                for (int c = 0; c < PW; ++c) st.p[s][c] = fma(st.e[s][j], u[c], j == 0 ? b[s][c] : st.p[s][c]);
+        }
+    }
+    template <int S, int SP, bool BOTH>
+    static __device__ __forceinline__ bool panel_real(Real<S>& st, double* A, int N, int lda, int k, int npan, int lane, int* fl, CgScaledProd& prod) {
+        const int k0 = k * PW;
+        CG_STAMP_START(20)
+        if (k + 1 == npan) {
+            steps_real<S, SP, BOTH, false>(st, k0, N - k0, lane, prod);
+            CG_STAMP_END(20)
+            return true;
+        }
+        steps_real<S, SP, BOTH, true>(st, k0, PW, lane, prod);
+        CG_STAMP(20)
+        next_real<S, SP, BOTH>(st, A, N, lda, k, lane, fl);
+        CG_STAMP_END(23)
+        return false;
+    }
+    template <int S>
+    static __device__ __forceinline__ void chain_real(double* A, int N, int lda, int lane, int* fl, double* res) {
+        const int npan = (N + PW - 1) / PW;
+        Real<S> st;
+        st.live[0] = N >= 64 ? ~0ull : ((1ull << N) - 1ull);
+        st.live[1] = (S == 2 && N > 64) ? (N >= 128 ? ~0ull : ((1ull << (N - 64)) - 1ull)) : 0ull;
+        st.swm = 0ull; st.pm = 1.0;
+        CgScaledProd prod; prod.init();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int row = lane + 64 * s;
+            const d2_t* q = (const d2_t*)(A + (row < N ? row : N - 1) * lda);
+#pragma unroll
+            for (int c = 0; c < PW / 2; ++c) { const d2_t v = q[c]; st.p[s][2 * c] = v[0]; st.p[s][2 * c + 1] = v[1]; }
+#pragma unroll
+            for (int c = 0; c < PW; ++c) st.e[s][c] = 0.0;
+        }
+        for (int k = 0; k < npan; ++k) {
+            bool done;
+            if (S == 1) done = panel_real<S, 0, false>(st, A, N, lda, k, npan, lane, fl, prod);
+            else {
+                int sp = (k * PW) >> 6;
+                if (!(sp ? st.live[S - 1] : st.live[0])) sp ^= 1;
+                const bool both = (sp ? st.live[0] : st.live[S - 1]) != 0ull;
+                if (sp == 0) done = both ? panel_real<S, 0, true>(st, A, N, lda, k, npan, lane, fl, prod) : panel_real<S, 0, false>(st, A, N, lda, k, npan, lane, fl, prod);
+                else done = both ? panel_real<S, S - 1, true>(st, A, N, lda, k, npan, lane, fl, prod) : panel_real<S, S - 1, false>(st, A, N, lda, k, npan, lane, fl, prod);
+            }
+            if (done) break;
+        }
+        if (lane == 0) res[0] = prod.logabs(true);
+    }
+
+    // ---------------------------------------------------------------- complex chain (one wave, n <= 64) ----------------------
+    struct Cplx {
+        double pr[PW], pi[PW], er[PW], ei[PW];
+        unsigned long long live;
+        int pl[PW];
+        CgCplx pm; int pe, parity;
+    };
+    template <bool FULL>
+    static __device__ __forceinline__ void steps_cplx(Cplx& st, int k0, int kb, int lane) {
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            if (FULL || j < kb) {
+                int cl = k0 + j;
+                const int key = seli(st.live, hi_abs(st.pr[j] * st.pr[j] + st.pi[j] * st.pi[j]));
+                const int mkk = __builtin_amdgcn_readlane(key, cl);
+                // (squared moduli: 16x = 4x in modulus = four binades of the high word)
+                if (!((st.live >> cl) & 1ull) || __ballot((unsigned)key > (unsigned)mkk + 0x00400000u)) {
+                    const unsigned kk = ((st.live >> lane) & 1ull) ? (unsigned)hi_abs(st.pr[j] * st.pr[j] + st.pi[j] * st.pi[j]) + 1u : 0u;
+                    const unsigned mx = cg_wave_max_u32(kk);
+                    cl = (int)__builtin_ctzll(__ballot(kk == mx));
+                }
+                st.pl[j] = cl;
+                st.parity += __builtin_popcountll(st.live & ((1ull << cl) - 1ull));   // position of the pivot among the live rows
+                st.live &= ~(1ull << cl);
+                double rpr[PW], rpi[PW];
+#pragma unroll
+                for (int jj = j; jj < PW; ++jj) { rpr[jj] = cg_readlane_f64(st.pr[jj], cl); rpi[jj] = cg_readlane_f64(st.pi[jj], cl); }
+                st.pm = cmul(st.pm, CgCplx{rpr[j], rpi[j]});
+                if ((j & 3) == 3 || (!FULL && j + 1 == kb)) {
+                    int ex; const double mxv = fmax(fabs(st.pm.re), fabs(st.pm.im)); (void)frexp(mxv, &ex);
+                    st.pm.re = ldexp(st.pm.re, -ex); st.pm.im = ldexp(st.pm.im, -ex); st.pe += ex;
+                }
+                const double rd = cg_fast_rcp1(rpr[j] * rpr[j] + rpi[j] * rpi[j]);
+                const double qr = rpr[j] * rd, qi = -rpi[j] * rd;      // 1 / pivot
+                const double lr = st.pr[j] * qr - st.pi[j] * qi, li = st.pr[j] * qi + st.pi[j] * qr;
+                st.pr[j] = lr; st.pi[j] = li;
+#pragma unroll
+                for (int jj = j + 1; jj < PW; ++jj) {
+                    st.pr[jj] = fma(li, rpi[jj], fma(-lr, rpr[jj], st.pr[jj]));
+                    st.pi[jj] = fma(-li, rpr[jj], fma(-lr, rpi[jj], st.pi[jj]));
+                }
+                // E = -L21 L11^-1 (the row operations on the identity columns)
+#pragma unroll
+                for (int c = 0; c < j; ++c) {
+                    const double ur = cg_readlane_f64(st.er[c], cl), ui = cg_readlane_f64(st.ei[c], cl);
+                    st.er[c] = fma(li, ui, fma(-lr, ur, st.er[c]));
+                    st.ei[c] = fma(-li, ur, fma(-lr, ui, st.ei[c]));
+                }
+                st.er[j] = -lr; st.ei[j] = -li;
+            } else { st.pl[j] = 0; st.er[j] = 0.0; st.ei[j] = 0.0; }
+        }
+    }
+    static __device__ __forceinline__ void chain_cplx(double* C, int n, int ldc, int lane, int* fl, double* res) {
+        const int npan = (n + PW - 1) / PW;
+        Cplx st;
+        st.live = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        st.pm = CgCplx{1.0, 0.0}; st.pe = 0; st.parity = 0;
+        const int rowc = lane < n ? lane : n - 1;                          // (clamped: lanes beyond the matrix read a valid row and are never live)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+            const d2_t v = *(const d2_t*)(C + 2 * (rowc * ldc + j));     // (n >= 8 on this path)
+            st.pr[j] = v[0]; st.pi[j] = v[1]; st.er[j] = 0.0; st.ei[j] = 0.0;
+        }
+        for (int k = 0; k < npan; ++k) {
+            const int k0 = k * PW;
+            CG_STAMP_START(25)
+            if (k + 1 == npan) { steps_cplx<false>(st, k0, n - k0, lane); CG_STAMP_END(25) break; }
+            steps_cplx<true>(st, k0, PW, lane);
+            CG_STAMP(25)
+#pragma unroll
+            for (int c = 0; c < PW; ++c) { st.er[c] = sel(st.live, st.er[c]); st.ei[c] = sel(st.live, st.ei[c]); }
+            if (lane < n) {
+#pragma unroll
+                for (int c = 0; c < PW; ++c) *(d2_t*)(C + 2 * (lane * ldc + k0 + c)) = d2_t{st.er[c], st.ei[c]};
+            }
+            if (lane == 0) {
+                i4_t* q = (i4_t*)(fl + O_PIVC + k0);
+                q[0] = i4_t{st.pl[0], st.pl[1], st.pl[2], st.pl[3]};
+                q[1] = i4_t{st.pl[4], st.pl[5], st.pl[6], st.pl[7]};
+                fl[O_LIVE_C + k] = live_tiles(st.live, 0ull);
+            }
+            cg_flag_post(fl + O_PUB_C, k + 1, lane);
+            CG_STAMP(26)
+            const int m0 = k0 + PW;
+            if (k > 0) cg_flag_wait(fl + O_APP + 8 + ((k + 1) >> 1), k);
+            CG_STAMP(27)
+            double br[PW], bi[PW];
+#pragma unroll
+            for (int c = 0; c < PW; ++c) {
+                const int cc = m0 + c < n ? m0 + c : n - 1;               // (columns beyond the matrix: never used)
+                const d2_t v = *(const d2_t*)(C + 2 * (rowc * ldc + cc));
+                br[c] = v[0]; bi[c] = v[1];
+            }
+            // p = b + E A12 with the pivot rows' entries read where they stand (wave-uniform addresses: broadcast reads)
+#pragma unroll
+            for (int j = 0; j < PW; ++j) {
+                const d2_t* q = (const d2_t*)(C + 2 * (st.pl[j] * ldc));
+#pragma unroll
+                for (int c = 0; c < PW; ++c) {
+                    const int cc = m0 + c < n ? m0 + c : n - 1;
+                    const d2_t u = q[cc];
+                    st.pr[c] = fma(-st.ei[j], u[1], fma(st.er[j], u[0], j == 0 ? br[c] : st.pr[c]));
+                    st.pi[c] = fma(st.ei[j], u[0], fma(st.er[j], u[1], j == 0 ? bi[c] : st.pi[c]));
+                }
+            }
+            CG_STAMP_END(28)
+        }
+        if (lane == 0) {
+            if (st.parity & 1) { st.pm.re = -st.pm.re; st.pm.im = -st.pm.im; }
+            res[1] = 0.5 * cg_log_ool(st.pm.re * st.pm.re + st.pm.im * st.pm.im) + (double)st.pe * 0.693147180559945309417232121458;
+            res[2] = cg_atan2_ool(st.pm.im, st.pm.re);
+        }
+    }
+
+    // ---------------------------------------------------------------- helper tasks: pure GEMMs on MFMA ------------------------
+    // block columns [c0, cend) (<= 16) += E[:, k0 .. k0+8) * A[pivot rows of the panel, block], over the live row tiles, two per trip
+    static __device__ __forceinline__ void task_real(double* A, int N, int lda, int k0, int c0, int cend, const int* piv, int tiles, int lane) {
+        const int col = lane & 15, kq = lane >> 4, bc = c0 + col;
+        const bool cok = bc < cend;
+        const int bcc = cok ? bc : c0;
+        double bv[PW / 4];
+#pragma unroll
+        for (int ks = 0; ks < PW / 4; ++ks) { const double v = A[piv[4 * ks + kq] * lda + bcc]; bv[ks] = cok ? v : 0.0; }
+        while (tiles) {
+            int t[2];
+            t[0] = __builtin_ctz(tiles); tiles &= tiles - 1;
+            t[1] = tiles ? __builtin_ctz(tiles) : -1; tiles &= tiles - 1;   // (0 & -1 = 0)
+            cg_d4_t c[2]; double av[2][PW / 4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (t[h] < 0) continue;
+                const int r0 = 16 * t[h], ar = r0 + col;
+                const int arc = ar < N ? ar : N - 1;
+#pragma unroll
+                for (int ks = 0; ks < PW / 4; ++ks) { const double v = A[arc * lda + k0 + 4 * ks + kq]; av[h][ks] = ar < N ? v : 0.0; }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int rr = r0 + kq + 4 * r; c[h][r] = (rr < N && cok) ? A[rr * lda + bc] : 0.0; }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (t[h] < 0) continue;
+#pragma unroll
+                for (int ks = 0; ks < PW / 4; ++ks) c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][ks], bv[ks], c[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (t[h] < 0) continue;
+                const int r0 = 16 * t[h];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int rr = r0 + kq + 4 * r; if (rr < N && cok) A[rr * lda + bc] = c[h][r]; }
+            }
+        }
+    }
+    static __device__ __forceinline__ void task_cplx(double* C, int n, int ldc, int k0, int c0, int cend, const int* piv, int tiles, int lane) {
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        const int col = lane & 15, kq = lane >> 4, bc = c0 + col;
+        const bool cok = bc < cend;
+        const int bcc = cok ? bc : c0;
+        double b_re[PW / 4], b_im[PW / 4];
+#pragma unroll
+        for (int ks = 0; ks < PW / 4; ++ks) {
+            const d2_t v = *(const d2_t*)(C + 2 * (piv[4 * ks + kq] * ldc + bcc));
+            b_re[ks] = cok ? v[0] : 0.0; b_im[ks] = cok ? v[1] : 0.0;
+        }
+        while (tiles) {
+            const int t = __builtin_ctz(tiles); tiles &= tiles - 1;
+            const int r0 = 16 * t, ar = r0 + col, arc = ar < n ? ar : n - 1;
+            double a_re[PW / 4], a_im[PW / 4];
+#pragma unroll
+            for (int ks = 0; ks < PW / 4; ++ks) {
+                const d2_t v = *(const d2_t*)(C + 2 * (arc * ldc + k0 + 4 * ks + kq));
+                a_re[ks] = ar < n ? v[0] : 0.0; a_im[ks] = ar < n ? v[1] : 0.0;
+            }
+            cg_d4_t cr, ci;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + kq + 4 * r; const bool ok = rr < n && cok;
+                const d2_t v = ok ? *(const d2_t*)(C + 2 * (rr * ldc + bc)) : d2_t{0.0, 0.0};
+                cr[r] = v[0]; ci[r] = v[1];
+            }
+#pragma unroll
+            for (int ks = 0; ks < PW / 4; ++ks) {
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re[ks], b_re[ks], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re[ks], b_im[ks], ci, 0, 0, 0);
+                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_im[ks], b_im[ks], cr, 0, 0, 0);
+                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im[ks], b_re[ks], ci, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = r0 + kq + 4 * r;
+                if (rr < n && cok) *(d2_t*)(C + 2 * (rr * ldc + bc)) = d2_t{cr[r], ci[r]};
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void cg_blocked_lu_dual2(const CgBlk& b, double* A, int N, int lda, double* C, int n, int ldc, double* res,
+                                                    double& logabs_real, double& logabs_c, double& arg_c) {
+    const int lane = b.tid & 63, wave = b.tid >> 6;
+    constexpr int PW = CG_LU_PW;
+    int* fl = (int*)(res + 4);
+    const int npr = (N + PW - 1) / PW, npc = (n + PW - 1) / PW;
+    for (int e = b.tid; e < 32; e += b.nthr) fl[e] = 0;
+    b.sync();
+    if (wave == 0) {
+        CG_STAMP_START(16)
+        if (N <= 64) CgLu2::chain_real<1>(A, N, lda, lane, fl, res); else CgLu2::chain_real<2>(A, N, lda, lane, fl, res);
+        CG_STAMP_END(16)
+    } else if (wave == 1) {
+        CG_STAMP_START(17)
+        CgLu2::chain_cplx(C, n, ldc, lane, fl, res);
+        CG_STAMP_END(17)
+    } else {
+        // helpers: lane l < 8 watches real block l, lanes 8..11 complex block l - 8; one ballot picks the task
+        int* claim = fl + CgLu2::O_CLAIM; int* app = fl + CgLu2::O_APP;
+        const int nbr = (N + 15) >> 4, nbc = (n + 15) >> 4;
+        const bool isr = lane < 8, mine = isr ? lane < nbr : (lane < 12 && lane - 8 < nbc);
+        const int j = isr ? lane : lane - 8;
+        const int limit = !mine ? 0 : (isr ? (2 * j < npr - 1 ? 2 * j : npr - 1) : (2 * j < npc - 1 ? 2 * j : npc - 1));   // panels this block receives
+        int idle = 0;
+        while (idle < (1 << 22)) {
+            const int pr = cg_flag_load(fl + CgLu2::O_PUB_R), pc = cg_flag_load(fl + CgLu2::O_PUB_C);
+            int q = 0, ap = 0;
+            if (lane < 12) {
+                q = __hip_atomic_load(claim + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ap = __hip_atomic_load(app + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const bool pending = mine && q < limit;
+            if (!__ballot(pending)) break;                               // every task of both matrices has been claimed
+            const bool ready = pending && (isr ? pr : pc) > q && ap >= q;
+            const unsigned long long mu = __ballot(ready && j == ((q + 2) >> 1)), me = __ballot(ready);
+            if (!me) { ++idle; __builtin_amdgcn_s_sleep(1); continue; }
+            const int pick = (int)__builtin_ctzll(mu ? mu : me);          // urgent (the block a chain waits for) first; real before complex
+            const int tq = __builtin_amdgcn_readlane(q, pick);
+            int got = 0;
+            if (lane == 0) got = atomicCAS(claim + pick, tq, tq + 1) == tq ? 1 : 0;
+            if (!__builtin_amdgcn_readfirstlane(got)) continue;          // another helper took it
+            CG_STAMP_START(19)
+            const int k0 = tq * PW;
+            if (pick < 8) {
+                const int c0 = 16 * pick > k0 + 2 * PW ? 16 * pick : k0 + 2 * PW, cend = 16 * pick + 16 < N ? 16 * pick + 16 : N;
+                if (c0 < cend) CgLu2::task_real(A, N, lda, k0, c0, cend, fl + CgLu2::O_PIVR + k0, cg_flag_load(fl + CgLu2::O_LIVE_R + tq), lane);
+            } else {
+                const int jb = pick - 8;
+                const int c0 = 16 * jb > k0 + 2 * PW ? 16 * jb : k0 + 2 * PW, cend = 16 * jb + 16 < n ? 16 * jb + 16 : n;
+                if (c0 < cend) CgLu2::task_cplx(C, n, ldc, k0, c0, cend, fl + CgLu2::O_PIVC + k0, cg_flag_load(fl + CgLu2::O_LIVE_C + tq), lane);
+            }
+            cg_flag_post(app + pick, tq + 1, lane);
             CG_STAMP_END(19)
         }
     }
