@@ -1250,7 +1250,7 @@ static CG_HD CgFastLds cg_fast_layout(int n, int D, int HS, int HT, bool alias, 
     if (alias && !small) {
         // large n: everything but z and the LU scratch is dead after the Jacobian assembly; kept contiguous so that the
         // Slater matrix fits over it (n = 57: 6626 doubles against 2 n^2 = 6498) and is factored WHILE J is factored.
-        o.z = take(n * D); o.perm = take(128);           // CG_LU_DUAL_DOUBLES: flags, pivots and live-tile masks of both LUs
+        o.z = take(n * D); o.perm = take(164);           // CG_LU_DUAL_DOUBLES: flags and per-panel records (pivot rows, live row tiles) of both LUs
         dead0 = t;
         o.sh = take(n * D); o.ch = take(n * D); o.sg1 = take(n * HS); o.sg2 = take(n * HS);
         o.wt = take(HT * (P + 1) + HS * D);

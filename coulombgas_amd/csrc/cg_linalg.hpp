@@ -1754,7 +1754,7 @@ __device__ __forceinline__ void cg_blocked_lu_logdet_complex(const CgBlk& b, dou
 //   dependency would give wrong numbers, never a hung GPU).  The arithmetic on each matrix is that of the sequential drivers
 //   in the same order: bitwise identical results.
 // res: CG_LU_DUAL_DOUBLES doubles of LDS.
-#define CG_LU_DUAL_DOUBLES 128
+#define CG_LU_DUAL_DOUBLES 164
 __device__ __forceinline__ int cg_flag_load(const int* f) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
@@ -1893,12 +1893,16 @@ __device__ __forceinline__ void cg_blocked_lu_dual(const CgBlk& b, double* A, in
 //     a pure MFMA GEMM whose B operand is gathered by pivot index -- no triangular solve, no exchanges.
 //   * a row tile whose 16 rows have all served as pivots is skipped by the helpers (`live` mask per panel).
 // Flags / task scheme as in the first generation.  res: CG_LU_DUAL_DOUBLES doubles of LDS, 16-byte aligned.
+#if !defined(CG_LU_TRACE)
+#define CG_LU_TRACE(chain, k)          /* tools/lu_bench: per-panel time stamps of the chain waves */
+#endif
 struct CgLu2 {
     static constexpr int PW = CG_LU_PW;
     typedef double d2_t __attribute__((ext_vector_type(2)));
     typedef int i4_t __attribute__((ext_vector_type(4)));
     // int offsets inside the flag area
-    static constexpr int O_PUB_R = 0, O_PUB_C = 1, O_CLAIM = 2, O_APP = 14, O_PIVR = 32, O_PIVC = 160, O_LIVE_R = 224, O_LIVE_C = 240;
+    static constexpr int O_PUB_R = 0, O_PUB_C = 1, O_CLAIM = 2, O_APP = 14;
+    static constexpr int REC = 12, O_REC_R = 32, O_REC_C = 32 + 16 * REC;   // per panel {pivot rows[8], live row tiles, -, -, -}: 16 real + 8 complex panels
 
     // per-lane select by a wave-uniform lane mask (the mask IS the condition register of the select)
     static __device__ __forceinline__ int seli(unsigned long long mask, int v) {
@@ -1912,13 +1916,12 @@ struct CgLu2 {
     static __device__ __forceinline__ int hi_abs(double v) { return (int)((unsigned)((unsigned long long)__double_as_longlong(v) >> 32) & 0x7fffffffu); }
     // row tiles (16 rows) that still hold a live row: bit t of the result (l0: rows 0..63, l1: rows 64..127)
     static __device__ __forceinline__ int live_tiles(unsigned long long l0, unsigned long long l1) {
-        int m = 0;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if ((l0 >> (16 * t)) & 0xffffull) m |= 1 << t;
-            if ((l1 >> (16 * t)) & 0xffffull) m |= 16 << t;
-        }
-        return m;
+        auto four = [](unsigned long long l) {
+            l |= l >> 8; l |= l >> 4; l |= l >> 2; l |= l >> 1;             // bit 0 of every 16-bit group = OR of the group
+            l &= 0x0001000100010001ull;
+            return (int)(((l * 0x0001000200040008ull) >> 48) & 0xfull);     // bits 0, 16, 32, 48 gathered into bits 0..3 (group g lands on bit 48 + g)
+        };
+        return four(l0) | (four(l1) << 4);
     }
 
     // ---------------------------------------------------------------- real chain (one wave) ----------------------------------
@@ -2029,11 +2032,11 @@ struct CgLu2 {
             }
         }
         if (lane == 0) {
-            i4_t* q = (i4_t*)(fl + O_PIVR + k0);
+            i4_t* q = (i4_t*)(fl + O_REC_R + REC * k);
+            const unsigned long long l0 = (st.live[0] & ~st.swm) | (st.live[1] & st.swm), l1 = (st.live[1] & ~st.swm) | (st.live[0] & st.swm);
             q[0] = i4_t{st.prow[0], st.prow[1], st.prow[2], st.prow[3]};
             q[1] = i4_t{st.prow[4], st.prow[5], st.prow[6], st.prow[7]};
-            const unsigned long long l0 = (st.live[0] & ~st.swm) | (st.live[1] & st.swm), l1 = (st.live[1] & ~st.swm) | (st.live[0] & st.swm);
-            fl[O_LIVE_R + k] = live_tiles(l0, l1);
+            q[2] = i4_t{live_tiles(l0, l1), 0, 0, 0};
         }
         cg_flag_post(fl + O_PUB_R, k + 1, lane);
         CG_STAMP(21)
@@ -2046,17 +2049,27 @@ struct CgLu2 {
 #pragma unroll
             for (int c = 0; c < PW / 2; ++c) { const d2_t v = q[c]; b[s][2 * c] = v[0]; b[s][2 * c + 1] = v[1]; }   // (columns >= N of the last panel: never used)
         }
-        // p = b + E A12, A12 = the pivot rows' entries of the new columns as they stand in LDS (wave-uniform addresses: broadcast reads)
+        // p = b + E A12, A12 = the pivot rows' entries of the new columns as they stand in LDS (wave-uniform addresses: broadcast reads);
+        // the reads of pivot row j + 1 are issued before the products of row j
+        d2_t u[2][PW / 2];
+        {
+            const d2_t* q = (const d2_t*)(A + st.prow[0] * lda + m0);
+#pragma unroll
+            for (int c = 0; c < PW / 2; ++c) u[0][c] = q[c];
+        }
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j < PW; ++j) {
-            const d2_t* q = (const d2_t*)(A + st.prow[j] * lda + m0);
-            double u[PW];
+            if (j + 1 < PW) {
+                const d2_t* q = (const d2_t*)(A + st.prow[j + 1] * lda + m0);
 #pragma unroll
-            for (int c = 0; c < PW / 2; ++c) { const d2_t v = q[c]; u[2 * c] = v[0]; u[2 * c + 1] = v[1]; }
+                for (int c = 0; c < PW / 2; ++c) u[(j + 1) & 1][c] = q[c];
+                asm volatile("" ::: "memory");
+            }
 #pragma unroll
             for (int s = S0; s < S1; ++s)
 #pragma unroll
-                for (int c = 0; c < PW; ++c) st.p[s][c] = fma(st.e[s][j], u[c], j == 0 ? b[s][c] : st.p[s][c]);
+                for (int c = 0; c < PW; ++c) st.p[s][c] = fma(st.e[s][j], u[j & 1][c >> 1][c & 1], j == 0 ? b[s][c] : st.p[s][c]);
         }
     }
     template <int S, int SP, bool BOTH>
@@ -2093,6 +2106,7 @@ struct CgLu2 {
         }
         for (int k = 0; k < npan; ++k) {
             bool done;
+            CG_LU_TRACE(0, k)
             if (S == 1) done = panel_real<S, 0, false>(st, A, N, lda, k, npan, lane, fl, prod);
             else {
                 int sp = (k * PW) >> 6;
@@ -2171,6 +2185,7 @@ struct CgLu2 {
         }
         for (int k = 0; k < npan; ++k) {
             const int k0 = k * PW;
+            CG_LU_TRACE(1, k)
             CG_STAMP_START(25)
             if (k + 1 == npan) { steps_cplx<false>(st, k0, n - k0, lane); CG_STAMP_END(25) break; }
             steps_cplx<true>(st, k0, PW, lane);
@@ -2182,33 +2197,63 @@ struct CgLu2 {
                 for (int c = 0; c < PW; ++c) *(d2_t*)(C + 2 * (lane * ldc + k0 + c)) = d2_t{st.er[c], st.ei[c]};
             }
             if (lane == 0) {
-                i4_t* q = (i4_t*)(fl + O_PIVC + k0);
+                i4_t* q = (i4_t*)(fl + O_REC_C + REC * k);
                 q[0] = i4_t{st.pl[0], st.pl[1], st.pl[2], st.pl[3]};
                 q[1] = i4_t{st.pl[4], st.pl[5], st.pl[6], st.pl[7]};
-                fl[O_LIVE_C + k] = live_tiles(st.live, 0ull);
+                q[2] = i4_t{live_tiles(st.live, 0ull), 0, 0, 0};
             }
             cg_flag_post(fl + O_PUB_C, k + 1, lane);
             CG_STAMP(26)
             const int m0 = k0 + PW;
             if (k > 0) cg_flag_wait(fl + O_APP + 8 + ((k + 1) >> 1), k);
             CG_STAMP(27)
-            double br[PW], bi[PW];
+            // p = b + E A12 with the pivot rows' entries read where they stand (wave-uniform addresses: broadcast reads).  The reads of
+            // pivot row j + 1 are issued before the products of row j (two rows of eight 16-byte reads in flight: the LDS latency is
+            // paid once, not per pair of reads)
+            if (m0 + PW <= n) {
+                const d2_t* qb = (const d2_t*)(C + 2 * (rowc * ldc + m0));
+                d2_t bv[PW], u[2][PW];
 #pragma unroll
-            for (int c = 0; c < PW; ++c) {
-                const int cc = m0 + c < n ? m0 + c : n - 1;               // (columns beyond the matrix: never used)
-                const d2_t v = *(const d2_t*)(C + 2 * (rowc * ldc + cc));
-                br[c] = v[0]; bi[c] = v[1];
-            }
-            // p = b + E A12 with the pivot rows' entries read where they stand (wave-uniform addresses: broadcast reads)
+                for (int c = 0; c < PW; ++c) bv[c] = qb[c];
+                {
+                    const d2_t* q = (const d2_t*)(C + 2 * (st.pl[0] * ldc + m0));
 #pragma unroll
-            for (int j = 0; j < PW; ++j) {
-                const d2_t* q = (const d2_t*)(C + 2 * (st.pl[j] * ldc));
+                    for (int c = 0; c < PW; ++c) u[0][c] = q[c];
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    if (j + 1 < PW) {
+                        const d2_t* q = (const d2_t*)(C + 2 * (st.pl[j + 1] * ldc + m0));
+#pragma unroll
+                        for (int c = 0; c < PW; ++c) u[(j + 1) & 1][c] = q[c];
+                        asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) {
+                        const d2_t uu = u[j & 1][c];
+                        st.pr[c] = fma(-st.ei[j], uu[1], fma(st.er[j], uu[0], j == 0 ? bv[c][0] : st.pr[c]));
+                        st.pi[c] = fma(st.ei[j], uu[0], fma(st.er[j], uu[1], j == 0 ? bv[c][1] : st.pi[c]));
+                    }
+                }
+            } else {                                                       // the last, narrower panel (once per factorisation): clamped columns
+                double br[PW], bi[PW];
 #pragma unroll
                 for (int c = 0; c < PW; ++c) {
                     const int cc = m0 + c < n ? m0 + c : n - 1;
-                    const d2_t u = q[cc];
-                    st.pr[c] = fma(-st.ei[j], u[1], fma(st.er[j], u[0], j == 0 ? br[c] : st.pr[c]));
-                    st.pi[c] = fma(st.ei[j], u[0], fma(st.er[j], u[1], j == 0 ? bi[c] : st.pi[c]));
+                    const d2_t v = *(const d2_t*)(C + 2 * (rowc * ldc + cc));
+                    br[c] = v[0]; bi[c] = v[1];
+                }
+#pragma unroll
+                for (int j = 0; j < PW; ++j) {
+                    const d2_t* q = (const d2_t*)(C + 2 * (st.pl[j] * ldc));
+#pragma unroll
+                    for (int c = 0; c < PW; ++c) {
+                        const int cc = m0 + c < n ? m0 + c : n - 1;
+                        const d2_t u = q[cc];
+                        st.pr[c] = fma(-st.ei[j], u[1], fma(st.er[j], u[0], j == 0 ? br[c] : st.pr[c]));
+                        st.pi[c] = fma(st.ei[j], u[0], fma(st.er[j], u[1], j == 0 ? bi[c] : st.pi[c]));
+                    }
                 }
             }
             CG_STAMP_END(28)
@@ -2221,37 +2266,43 @@ struct CgLu2 {
     }
 
     // ---------------------------------------------------------------- helper tasks: pure GEMMs on MFMA ------------------------
-    // block columns [c0, cend) (<= 16) += E[:, k0 .. k0+8) * A[pivot rows of the panel, block], over the live row tiles, two per trip
-    static __device__ __forceinline__ void task_real(double* A, int N, int lda, int k0, int c0, int cend, const int* piv, int tiles, int lane) {
+    // block columns [c0, cend) (<= 16) += E[:, k0 .. k0+8) * A[pivot rows of the panel, block], over the live row tiles.  Loads are never
+    // predicated (row / column indices beyond the matrix are clamped: what they produce lands in accumulator rows / columns that are
+    // not stored), four tiles per trip so that the LDS latency is paid once per 8 MFMAs.
+    static __device__ __forceinline__ void task_real(double* A, int N, int lda, int k0, int c0, int cend, const int* rec, int lane) {
         const int col = lane & 15, kq = lane >> 4, bc = c0 + col;
         const bool cok = bc < cend;
         const int bcc = cok ? bc : c0;
-        double bv[PW / 4];
-#pragma unroll
-        for (int ks = 0; ks < PW / 4; ++ks) { const double v = A[piv[4 * ks + kq] * lda + bcc]; bv[ks] = cok ? v : 0.0; }
+        const int p0 = rec[kq], p1 = rec[4 + kq];
+        int tiles = __builtin_amdgcn_readfirstlane(rec[8]);
+        const double bv0 = A[p0 * lda + bcc], bv1 = A[p1 * lda + bcc];
+        constexpr int T = 4;
         while (tiles) {
-            int t[2];
-            t[0] = __builtin_ctz(tiles); tiles &= tiles - 1;
-            t[1] = tiles ? __builtin_ctz(tiles) : -1; tiles &= tiles - 1;   // (0 & -1 = 0)
-            cg_d4_t c[2]; double av[2][PW / 4];
+            int t[T];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < T; ++h) { t[h] = tiles ? __builtin_ctz(tiles) : -1; tiles &= tiles - 1; }   // (0 & -1 = 0)
+            cg_d4_t c[T]; double av[T][2];
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
                 if (t[h] < 0) continue;
-                const int r0 = 16 * t[h], ar = r0 + col;
-                const int arc = ar < N ? ar : N - 1;
+                const int r0 = 16 * t[h], ar = r0 + col < N ? r0 + col : N - 1;
+                const double* pa = A + ar * lda + k0 + kq;
+                av[h][0] = pa[0]; av[h][1] = pa[4];
 #pragma unroll
-                for (int ks = 0; ks < PW / 4; ++ks) { const double v = A[arc * lda + k0 + 4 * ks + kq]; av[h][ks] = ar < N ? v : 0.0; }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const int rr = r0 + kq + 4 * r; c[h][r] = (rr < N && cok) ? A[rr * lda + bc] : 0.0; }
+                for (int r = 0; r < 4; ++r) { const int rr = r0 + kq + 4 * r; c[h][r] = A[(rr < N ? rr : N - 1) * lda + bcc]; }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < T; ++h) {
                 if (t[h] < 0) continue;
-#pragma unroll
-                for (int ks = 0; ks < PW / 4; ++ks) c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][ks], bv[ks], c[h], 0, 0, 0);
+                c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][0], bv0, c[h], 0, 0, 0);
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                c[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][1], bv1, c[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
                 if (t[h] < 0) continue;
                 const int r0 = 16 * t[h];
 #pragma unroll
@@ -2259,44 +2310,65 @@ struct CgLu2 {
             }
         }
     }
-    static __device__ __forceinline__ void task_cplx(double* C, int n, int ldc, int k0, int c0, int cend, const int* piv, int tiles, int lane) {
-        typedef double d2_t __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void task_cplx(double* C, int n, int ldc, int k0, int c0, int cend, const int* rec, int lane) {
         const int col = lane & 15, kq = lane >> 4, bc = c0 + col;
         const bool cok = bc < cend;
         const int bcc = cok ? bc : c0;
-        double b_re[PW / 4], b_im[PW / 4];
-#pragma unroll
-        for (int ks = 0; ks < PW / 4; ++ks) {
-            const d2_t v = *(const d2_t*)(C + 2 * (piv[4 * ks + kq] * ldc + bcc));
-            b_re[ks] = cok ? v[0] : 0.0; b_im[ks] = cok ? v[1] : 0.0;
-        }
+        const int p0 = rec[kq], p1 = rec[4 + kq];
+        int tiles = __builtin_amdgcn_readfirstlane(rec[8]);
+        const d2_t b0 = *(const d2_t*)(C + 2 * (p0 * ldc + bcc)), b1 = *(const d2_t*)(C + 2 * (p1 * ldc + bcc));
+        constexpr int T = 2;
         while (tiles) {
-            const int t = __builtin_ctz(tiles); tiles &= tiles - 1;
-            const int r0 = 16 * t, ar = r0 + col, arc = ar < n ? ar : n - 1;
-            double a_re[PW / 4], a_im[PW / 4];
+            int t[T];
 #pragma unroll
-            for (int ks = 0; ks < PW / 4; ++ks) {
-                const d2_t v = *(const d2_t*)(C + 2 * (arc * ldc + k0 + 4 * ks + kq));
-                a_re[ks] = ar < n ? v[0] : 0.0; a_im[ks] = ar < n ? v[1] : 0.0;
-            }
-            cg_d4_t cr, ci;
+            for (int h = 0; h < T; ++h) { t[h] = tiles ? __builtin_ctz(tiles) : -1; tiles &= tiles - 1; }
+            cg_d4_t cr[T], ci[T]; d2_t a0[T], a1[T];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = r0 + kq + 4 * r; const bool ok = rr < n && cok;
-                const d2_t v = ok ? *(const d2_t*)(C + 2 * (rr * ldc + bc)) : d2_t{0.0, 0.0};
-                cr[r] = v[0]; ci[r] = v[1];
-            }
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                const int r0 = 16 * t[h], ar = r0 + col < n ? r0 + col : n - 1;
+                const d2_t* pa = (const d2_t*)(C + 2 * (ar * ldc + k0 + kq));
+                a0[h] = pa[0]; a1[h] = pa[4];
 #pragma unroll
-            for (int ks = 0; ks < PW / 4; ++ks) {
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re[ks], b_re[ks], cr, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re[ks], b_im[ks], ci, 0, 0, 0);
-                cr = __builtin_amdgcn_mfma_f64_16x16x4f64(-a_im[ks], b_im[ks], cr, 0, 0, 0);
-                ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im[ks], b_re[ks], ci, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + kq + 4 * r;
+                    const d2_t v = *(const d2_t*)(C + 2 * ((rr < n ? rr : n - 1) * ldc + bcc));
+                    cr[h][r] = v[0]; ci[h][r] = v[1];
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = r0 + kq + 4 * r;
-                if (rr < n && cok) *(d2_t*)(C + 2 * (rr * ldc + bc)) = d2_t{cr[r], ci[r]};
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h][0], b0[0], cr[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h][0], b0[1], ci[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a0[h][1], b0[1], cr[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h][1], b0[0], ci[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h][0], b1[0], cr[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h][0], b1[1], ci[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                cr[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a1[h][1], b1[1], cr[h], 0, 0, 0);
+                ci[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h][1], b1[0], ci[h], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < T; ++h) {
+                if (t[h] < 0) continue;
+                const int r0 = 16 * t[h];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rr = r0 + kq + 4 * r;
+                    if (rr < n && cok) *(d2_t*)(C + 2 * (rr * ldc + bc)) = d2_t{cr[h][r], ci[h][r]};
+                }
             }
         }
     }
@@ -2327,18 +2399,20 @@ __device__ __forceinline__ void cg_blocked_lu_dual2(const CgBlk& b, double* A, i
         const int limit = !mine ? 0 : (isr ? (2 * j < npr - 1 ? 2 * j : npr - 1) : (2 * j < npc - 1 ? 2 * j : npc - 1));   // panels this block receives
         int idle = 0;
         while (idle < (1 << 22)) {
-            const int pr = cg_flag_load(fl + CgLu2::O_PUB_R), pc = cg_flag_load(fl + CgLu2::O_PUB_C);
-            int q = 0, ap = 0;
-            if (lane < 12) {
-                q = __hip_atomic_load(claim + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                ap = __hip_atomic_load(app + lane, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            // every flag in ONE LDS round trip (plain loads: LDS is coherent inside the workgroup, and what a flag guards is read only
+            // after the decision that depends on its value)
+            const int lc = lane < 12 ? lane : 0;
+            const int q = *(volatile const int*)(claim + lc), ap = *(volatile const int*)(app + lc), pub = *(volatile const int*)(fl + (isr ? 0 : 1));
             const bool pending = mine && q < limit;
             if (!__ballot(pending)) break;                               // every task of both matrices has been claimed
-            const bool ready = pending && (isr ? pr : pc) > q && ap >= q;
-            const unsigned long long mu = __ballot(ready && j == ((q + 2) >> 1)), me = __ballot(ready);
+            const bool ready = pending && pub > q && ap >= q;
+            const unsigned long long me = __ballot(ready);
             if (!me) { ++idle; __builtin_amdgcn_s_sleep(1); continue; }
-            const int pick = (int)__builtin_ctzll(mu ? mu : me);          // urgent (the block a chain waits for) first; real before complex
+            // the block a chain needs next (j = (q + 2) / 2) first, then the rest; real before complex.  (Measured and dropped, tools/lu_bench:
+            // earliest-deadline order, serving the block a chain is stalled on first, helpers with a preferred matrix -- 108 k cycles
+            // per pair at n = 57 with this order against 111 - 120 k.)
+            const unsigned long long mu = __ballot(ready && j == ((q + 2) >> 1));
+            const int pick = (int)__builtin_ctzll(mu ? mu : me);
             const int tq = __builtin_amdgcn_readlane(q, pick);
             int got = 0;
             if (lane == 0) got = atomicCAS(claim + pick, tq, tq + 1) == tq ? 1 : 0;
@@ -2347,11 +2421,11 @@ __device__ __forceinline__ void cg_blocked_lu_dual2(const CgBlk& b, double* A, i
             const int k0 = tq * PW;
             if (pick < 8) {
                 const int c0 = 16 * pick > k0 + 2 * PW ? 16 * pick : k0 + 2 * PW, cend = 16 * pick + 16 < N ? 16 * pick + 16 : N;
-                if (c0 < cend) CgLu2::task_real(A, N, lda, k0, c0, cend, fl + CgLu2::O_PIVR + k0, cg_flag_load(fl + CgLu2::O_LIVE_R + tq), lane);
+                if (c0 < cend) CgLu2::task_real(A, N, lda, k0, c0, cend, fl + CgLu2::O_REC_R + CgLu2::REC * tq, lane);
             } else {
                 const int jb = pick - 8;
                 const int c0 = 16 * jb > k0 + 2 * PW ? 16 * jb : k0 + 2 * PW, cend = 16 * jb + 16 < n ? 16 * jb + 16 : n;
-                if (c0 < cend) CgLu2::task_cplx(C, n, ldc, k0, c0, cend, fl + CgLu2::O_PIVC + k0, cg_flag_load(fl + CgLu2::O_LIVE_C + tq), lane);
+                if (c0 < cend) CgLu2::task_cplx(C, n, ldc, k0, c0, cend, fl + CgLu2::O_REC_C + CgLu2::REC * tq, lane);
             }
             cg_flag_post(app + pick, tq + 1, lane);
             CG_STAMP_END(19)

@@ -10,6 +10,10 @@
 #include <vector>
 #include <complex>
 #include <algorithm>
+#if defined(LU_TRACE)
+__device__ unsigned long long lu_trace[2][32];
+#define CG_LU_TRACE(chain, k) if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) lu_trace[chain][k] = __builtin_readcyclecounter();
+#endif
 #include "../../coulombgas_amd/csrc/cg_common.hpp"
 #include "../../coulombgas_amd/csrc/cg_linalg.hpp"
 
@@ -132,6 +136,10 @@ int main(int argc, char** argv) {
     }
     printf("variant %d n=%d N=%d nt=%d kind=%d: %.0f cycles per dual LU (median WG; min %.0f max %.0f)   err logabsJ %.2e logabsD %.2e argD %.2e  (ref %.6f %.6f %.6f)\n",
            LU_VARIANT, n, N, nt, kind, (double)cyc[WG / 2] / reps, (double)cyc[0] / reps, (double)cyc[WG - 1] / reps, e0, e1, e2, rl, cl_, ca);
+#if defined(LU_TRACE)
+    { unsigned long long tr[2][32]; CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(lu_trace), sizeof(tr)));
+      for (int c = 0; c < 2; ++c) { printf("  chain %d panel durations:", c); const int np = ((c ? n : N) + 7) / 8; for (int k = 0; k + 1 < np; ++k) printf(" %lld", (long long)(tr[c][k + 1] - tr[c][k])); printf("\n"); } }
+#endif
 #if defined(CG_STAMPS)
     unsigned long long st[64];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(cg_stamp_acc), sizeof(st)));
