@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 57, nt = argc > 2 ? atoi(argv[2]) : 512, reps = argc > 3 ? atoi(argv[3]) : 20;
     const int kind = argc > 4 ? atoi(argv[4]) : 0;
     const int nN = argc > 5 ? atoi(argv[5]) : n;      // size (in particles) of the real matrix if different
-    const int N = 2 * nN, WG = 256;
+    const int N = 2 * nN, WG = nt == 64 ? 2048 : 256;   // one-wave workgroups: eight per CU, two per SIMD, as k_mcmc runs them at n = 13
     std::vector<double> A(N * N), C(2 * n * n), tab(CG_TAB_DOUBLES);
     cg_tab_fill(tab.data());
     srand(1234 + kind);
@@ -122,9 +122,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
     const size_t lds = 8 * (size_t)(CG_TAB_DOUBLES + ((N * N + 1) & ~1) + 2 * n * n + 512);
     CK(hipFuncSetAttribute((const void*)k_lu, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t ev0, ev1; CK(hipEventCreate(&ev0)); CK(hipEventCreate(&ev1)); float ms = 0;
     for (int it = 0; it < 3; ++it) {
+        CK(hipEventRecord(ev0, 0));
         hipLaunchKernelGGL(k_lu, dim3(WG), dim3(nt), lds, 0, dtab, dA, dC, N, n, reps, dout, dcyc);
+        CK(hipEventRecord(ev1, 0));
         CK(hipDeviceSynchronize());
+        CK(hipEventElapsedTime(&ms, ev0, ev1));
     }
     std::vector<double> out(WG * 3); std::vector<unsigned long long> cyc(WG);
     CK(hipMemcpy(out.data(), dout, out.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(cyc.data(), dcyc, cyc.size() * 8, hipMemcpyDeviceToHost));
@@ -134,8 +138,8 @@ int main(int argc, char** argv) {
         e0 = std::max(e0, fabs(out[3 * w] - rl)); e1 = std::max(e1, fabs(out[3 * w + 1] - cl_));
         e2 = std::max(e2, fabs(remainder(out[3 * w + 2] - ca, 2 * M_PI)));
     }
-    printf("variant %d n=%d N=%d nt=%d kind=%d: %.0f cycles per dual LU (median WG; min %.0f max %.0f)   err logabsJ %.2e logabsD %.2e argD %.2e  (ref %.6f %.6f %.6f)\n",
-           LU_VARIANT, n, N, nt, kind, (double)cyc[WG / 2] / reps, (double)cyc[0] / reps, (double)cyc[WG - 1] / reps, e0, e1, e2, rl, cl_, ca);
+    printf("variant %d n=%d N=%d nt=%d kind=%d (%d WGs, kernel %.3f ms): %.0f cycles per dual LU (median WG; min %.0f max %.0f)   err logabsJ %.2e logabsD %.2e argD %.2e  (ref %.6f %.6f %.6f)\n",
+           LU_VARIANT, n, N, nt, kind, WG, ms, (double)cyc[WG / 2] / reps, (double)cyc[0] / reps, (double)cyc[WG - 1] / reps, e0, e1, e2, rl, cl_, ca);
 #if defined(LU_TRACE)
     { unsigned long long tr[2][32]; CK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(lu_trace), sizeof(tr)));
       for (int c = 0; c < 2; ++c) { printf("  chain %d panel durations:", c); const int np = ((c ? n : N) + 7) / 8; for (int k = 0; k + 1 < np; ++k) printf(" %lld", (long long)(tr[c][k + 1] - tr[c][k])); printf("\n"); } }
