@@ -161,6 +161,7 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
         x_d.version += 1                                   # (defeats the engine's score cache: time the kernel, not the look-up)
         eng.scores_compute_d(x_d, s_d)
     k = {"grad_laplacian (k_grad_lap2, Hutchinson-split)": med(lambda: eng.grad_laplacian_d(x_d, s_d, 2, v_d)),
+         "grad_laplacian (k_grad_lap2, exact Laplacian: n d basis jet passes, src/logpsi.py:63-106)": med(lambda: eng.grad_laplacian_d(x_d, s_d, 0, None), reps=1),
          "scores (k_scores)": med(scores),
          "quantum Fisher matrix + mean score (k_fisher, reductions)": med(lambda: eng.scores_fisher_d(pack, 0, P * P))}
     eng.set_ewald(10, cg.kpoints(dim, 15), 10.0)
@@ -176,7 +177,8 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from flop_count import grad_lap_flops, scores_flops
-        fl = {"grad_laplacian (k_grad_lap2, Hutchinson-split)": grad_lap_flops(n, dim, mode=2), "scores (k_scores)": scores_flops(n, dim)}
+        fl = {"grad_laplacian (k_grad_lap2, Hutchinson-split)": grad_lap_flops(n, dim, mode=2), "scores (k_scores)": scores_flops(n, dim),
+              "grad_laplacian (k_grad_lap2, exact Laplacian: n d basis jet passes, src/logpsi.py:63-106)": grad_lap_flops(n, dim, mode=0)}
         out["roofline"] = {kk: {"flop_per_walker": fl[kk], "achieved_tflops": fl[kk] * B / (k[kk] * 1e-3) / 1e12,
                                 "frac_of_fp64_peak": fl[kk] * B / (k[kk] * 1e-3) / 1e12 / peak_tflops} for kk in fl}
         out["roofline"]["note"] = "structured flop counts of tools/flop_count.py (FMA = 2 flops, transcendentals not counted), peak = measured fp64 rate %.1f TFLOP/s" % peak_tflops
@@ -213,6 +215,68 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
     except Exception as e:                                   # noqa: BLE001 -- a reporting extra must not lose the metric line
         out["hybrid_epoch_ms"] = None; out["hybrid_epoch"] = "failed: %r" % (e,)
     out["seconds"] = time.perf_counter() - t0
+    return out
+
+
+def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
+    """OUTSIDE the timed region, extra key `shapes`: BASELINE configs 4 and 5 -- the only configurations the reference published runs for
+    (data/n_29_*, n_57_*) -- at their per-GPU batch: one sampling call (k_mcmc, HIP events), the two derivative kernels and whole SR
+    epochs of coulombgas_amd.train, so that the driver-timed record carries them too (profiles/ holds the same numbers per round)."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine, DeviceArray
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from flop_count import grad_lap_flops, scores_flops
+    out = {}
+    for key, n, B, Emax, B_exact in (("n29", 29, 2048, 25, 256), ("n57", 57, 512, 49, 0)):
+        t0 = time.perf_counter()
+        L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
+        eng = Engine(n, 2, 2, 16, 16, L, sp)
+        try:
+            eng.set_params(theta); eng.device_mode(True)
+            d_x = eng.alloc((B, n, 2)).upload(x); d_s = eng.alloc((B, n), np.int32).upload(sidx); d_lp = eng.alloc((B,))
+            ts = []
+            for it in range(5):                                # two thermalisation rounds, three timed calls
+                eng.timer_start()
+                eng.mcmc_dev(d_x, d_s, B, mc_steps, stddev, seed=77 + it, walker_offset=0, logp_buf=d_lp)
+                ts.append(eng.timer_stop()); eng.wrap_dev(d_x, B)
+            k_ms = sorted(ts[2:])[1]
+            fl = FLOPS_PER_WALKER_STEP[n]
+            r = {"workload": "n=%d dim=2 Emax=%d batch=%d mc_steps=%d (per-GPU shape of BASELINE config %d)" % (n, Emax, B, mc_steps, 4 if n == 29 else 5),
+                 "kernel_ms": k_ms, "walker_steps_per_s": B * mc_steps / (k_ms * 1e-3),
+                 "frac": fl * B * mc_steps / (k_ms * 1e-3) / 1e12 / peak_tflops, "finite": bool(np.isfinite(d_lp.download()).all())}
+            eng.device_mode(False)
+            x_d = DeviceArray.from_numpy(eng, d_x.download()); s_d = DeviceArray.from_numpy(eng, sidx, np.int32)
+            v_d = eng.randn_d("hutch_v", x.shape, 4321)
+
+            def med(fn, reps=3):
+                fn(); eng.sync(); tt = []
+                for _ in range(reps):
+                    eng.timer_start(); fn(); tt.append(eng.timer_stop())
+                return sorted(tt)[len(tt) // 2]
+
+            def scores():
+                x_d.version += 1
+                eng.scores_compute_d(x_d, s_d)
+            gl = med(lambda: eng.grad_laplacian_d(x_d, s_d, 2, v_d)); sc = med(scores)
+            r["grad_laplacian_ms"] = gl; r["scores_ms"] = sc
+            r["grad_laplacian_frac"] = grad_lap_flops(n, 2, mode=2) * B / (gl * 1e-3) / 1e12 / peak_tflops
+            r["scores_frac"] = scores_flops(n, 2) * B / (sc * 1e-3) / 1e12 / peak_tflops
+            if B_exact:                                        # the reference's default (exact) Laplacian, on a slice of the batch
+                xe = DeviceArray.from_numpy(eng, x_d.numpy()[:B_exact]); se = DeviceArray.from_numpy(eng, sidx[:B_exact], np.int32)
+                ge = med(lambda: eng.grad_laplacian_d(xe, se, 0, None), reps=1)
+                r["grad_laplacian_exact"] = {"walkers": B_exact, "ms": ge,
+                                             "frac": grad_lap_flops(n, 2, mode=0) * B_exact / (ge * 1e-3) / 1e12 / peak_tflops}
+        finally:
+            eng.close()
+        flow = cg.FermiNet(2, 16, 16, L)
+        marks = [time.perf_counter()]
+        cg.train(flow, flow.unravel(theta, 2), sp, n, 2, L, rs=10.0, beta=1 / (4 * 0.15), batch=B, epochs=5, sampler=cg.GroundStateSampler(n, sp.shape[0]),
+                 log_prob=cg.GroundStateSampler(n, sp.shape[0]).log_prob, sr=(1e-3, 1e-3), mc_therm=1, mc_steps=mc_steps, seed=3,
+                 log=lambda row: marks.append(time.perf_counter()))
+        ep = sorted(np.diff(marks)[2:] * 1e3)
+        r["epoch_ms"] = float(ep[len(ep) // 2])
+        r["seconds"] = time.perf_counter() - t0
+        out[key] = r
     return out
 
 
@@ -342,12 +406,18 @@ def main():
         cpu = None
         energy = None
         update = None
+        shapes = None
         side_errors = []
         if world == 1 and not args.no_update_extras:
             try:                               # the metric line must survive a failing extra (reported, exit code 1 afterwards)
                 update = update_path_extras(eng, n, dim, L, sp, theta, sidx, x_final, peak, mc_steps=args.mc_steps)
             except Exception as e:             # noqa: BLE001
                 update = {"error": repr(e)}; side_errors.append("update_path")
+        if world == 1 and not args.no_update_extras and n == 13:
+            try:
+                shapes = production_shapes(peak, mc_steps=args.mc_steps, stddev=args.mc_stddev)
+            except Exception as e:             # noqa: BLE001
+                shapes = {"error": repr(e)}; side_errors.append("shapes")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 _, _, _, sidx0, x0 = synthetic(n, dim, B, args.Emax, 0)
@@ -369,7 +439,7 @@ def main():
                           "walkers_per_gpu": B, "mc_steps": args.mc_steps, "threads_per_walker": eng.launch_info()["threads"],
                           "lds_bytes_per_walker": eng.launch_info()["lds_bytes"]},
                "accept_rate": accept, "finite": ok, "comm": comm_kind, "roofline": roofline, "cpu_baseline": cpu,
-               "energy": energy, "update_path": update}
+               "energy": energy, "update_path": update, "shapes": shapes}
         print(json.dumps(out), flush=True)
         if side_errors:
             print("bench.py: %s failed (see the JSON line)" % ", ".join(side_errors), file=sys.stderr)

@@ -876,6 +876,48 @@ def test_grad_laplacian_n57_all_memory_placements():
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["golden_n57_d2.npz", "golden_n49_d2.npz"])
+def test_two_launch_chunks_at_the_production_batch(name):
+    """BASELINE config 5's per-GPU batch (512 walkers) at n = 57 and n = 49: above N = 64 the derivative kernels run in launches of
+    one workgroup per CU (256 walkers: csrc/cg_k_derivs.inc), so walkers 256 ... 511 go through a SECOND launch that reuses the
+    workspace slots of the first.  (i) determinism; (ii) batch independence bit for bit: rows 256 ... of the full call == the
+    call on x[256:] alone; (iii) the oracle's golden walkers placed INSIDE the second chunk (and one in the first) reproduce the
+    golden gradient / Laplacian / theta-VJP; (iv) the per-sample scores of the second chunk == those of the walkers alone."""
+    from coulombgas_amd.engine import Engine
+    g = np.load(GOLDEN_DIR + "/" + name)
+    n, dim, L = int(g["n"]), int(g["dim"]), float(g["L"])
+    M = g["sp_indices"].shape[0]
+    eng = Engine(n, dim, 2, 16, 16, L, g["sp_indices"])
+    eng.set_params(g["theta"])
+    B = 512
+    rng = np.random.default_rng(n)
+    x = walkers(rng, B, n, dim, L); sidx = state_indices(rng, B, n, M); v = rng.standard_normal(x.shape)
+    rows = {7: 0, 300: 0, 511: 1}                            # batch row -> golden walker
+    for r, k in rows.items():
+        x[r], sidx[r], v[r] = g["x"][k], g["state_idx"][k], g["v"][k]
+    rel = lambda a, b: np.abs(a - b).max() / max(1.0, np.abs(b).max())
+    gr, lp = eng.grad_laplacian(x, sidx, 2, v)
+    gr2, lp2 = eng.grad_laplacian(x, sidx, 2, v)
+    assert np.array_equal(gr, gr2) and np.array_equal(lp, lp2)
+    gt, lt = eng.grad_laplacian(x[256:], sidx[256:], 2, v[256:])
+    assert np.array_equal(gr[256:], gt) and np.array_equal(lp[256:], lt)
+    for r, k in rows.items():
+        assert rel(gr[r], g["grad_split"][k]) < 1e-10 and rel(lp[r], g["lap_split"][k]) < 1e-9
+    gh, lh = eng.grad_laplacian(x, sidx, 1, v)
+    for r, k in rows.items():
+        assert rel(gh[r], g["grad_hutch"][k]) < 1e-10 and rel(lh[r], g["lap_hutch"][k]) < 1e-9
+    # theta-VJP with the golden weights on the golden walkers of the SECOND chunk only
+    w_re, w_im = np.zeros(B), np.zeros(B)
+    w_re[300], w_im[300], w_re[511], w_im[511] = g["w_re"][0], g["w_im"][0], g["w_re"][1], g["w_im"][1]
+    assert rel(eng.param_vjp(x, sidx, w_re, w_im), g["vjp"]) < 1e-10
+    assert rel(eng.param_vjp(x, sidx, w_re, w_im, use_scores=False), g["vjp"]) < 1e-10
+    sc = eng.quantum_score(x, sidx)
+    sc2 = eng.quantum_score(x, sidx)
+    st = eng.quantum_score(x[256:], sidx[256:])
+    assert np.array_equal(sc, sc2) and np.array_equal(sc[256:], st) and np.isfinite(sc).all()
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # f2: the autoregressive Transformer density matrix on the device (cg_van_sample / cg_van_log_prob)
 # ---------------------------------------------------------------------------------------------
