@@ -9,6 +9,8 @@ Philox streams); the only collective is the scalar accept-rate mean (src/MCMC.py
 
 Launch: `python bench.py --gpus 1 --steps K --warmup W` or
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+(any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT will do: bench.py itself does not import
+torch.distributed -- the RCCL id travels over one TCP exchange, barrier and MAX over ranks through cg_allreduce_mean).
 Rank 0 prints ONE JSON line.
 """
 import argparse, json, os, sys, time
@@ -300,14 +302,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run" % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch one process per GPU (e.g. torch.distributed.run)" % (args.gpus, world), file=sys.stderr)
             sys.exit(2)
-    dist = None
     force_dist = os.environ.get("CG_FORCE_DIST") == "1"        # exercise the N > 1 code path on a 1-GPU box
-    if world > 1 or force_dist:
-        import torch, torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     from coulombgas_amd import utils
     from coulombgas_amd.engine import Engine
@@ -321,8 +318,7 @@ def main():
         eng.set_block_threads(args.threads)
     comm_kind = "none"
     if world > 1 or force_dist:
-        # the library's own RCCL path (cg_comm_* / cg_allreduce_mean) or nothing: a broken communicator must fail the run,
-        # not hand the scaling curve to torch.distributed
+        # the library's own RCCL path (cg_comm_* / cg_allreduce_mean) or nothing: a broken communicator must fail the run
         comm = RcclComm(eng, rank, world); comm_kind = "rccl via cg_allreduce_mean"
     else:
         comm = NullComm()
@@ -333,18 +329,15 @@ def main():
     d_lp = eng.alloc((B,))
     d_acc = eng.alloc((16,))
 
-    def barrier():
+    def barrier():                                             # every rank here, every stream drained (a one-element all-reduce)
         eng.sync()
-        if dist is not None:
-            import torch
-            dist.barrier(); torch.cuda.synchronize()
+        comm.barrier()
 
     def sampling_call(it):
         eng.mcmc_dev(d_x, d_s, B, args.mc_steps, args.mc_stddev, seed=42 + it, walker_offset=rank * B, logp_buf=d_lp)
         eng.wrap_dev(d_x, B)                                   # src/VMC.py:24
-        if world > 1 or force_dist:                            # src/MCMC.py:39 pmean of the accept rate
-            rate = eng.mcmc_accepts() / float(args.mc_steps * B)
-            return comm.pmean(rate)
+        if world > 1 or force_dist:                            # src/MCMC.py:39: pmean of the accept rate, formed and reduced on the device
+            return comm.accept_rate(eng, args.mc_steps * B)
         return None
 
     for it in range(args.warmup):                              # thermalisation rounds (main.py:241-246)
@@ -358,15 +351,11 @@ def main():
         kernel_ms += eng.timer_stop()                          # HIP events on the kernel's own stream
         eng.wrap_dev(d_x, B)
         if world > 1 or force_dist:
-            comm.pmean(eng.mcmc_accepts() / float(args.mc_steps * B))
+            comm.accept_rate(eng, args.mc_steps * B)
     barrier()
     elapsed = time.perf_counter() - t0
     accept = eng.mcmc_accepts() / float(args.mc_steps * B)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = comm.pmax(elapsed)                               # MAX over the ranks
 
     # sanity of the timed state: finite log-probabilities (a NaN chain would still "run fast")
     lp = d_lp.download()
@@ -444,9 +433,7 @@ def main():
         if side_errors:
             print("bench.py: %s failed (see the JSON line)" % ", ".join(side_errors), file=sys.stderr)
             ok = False
-    if dist is not None:
-        comm.close()
-        dist.destroy_process_group()
+    comm.close()
     eng.close()
     if not ok:
         sys.exit(1)

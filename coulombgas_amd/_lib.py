@@ -54,6 +54,7 @@ PROTOTYPES = {
     "cg_mcmc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_uint64,
                           C.c_void_p, C.c_void_p, C.c_void_p, c_lp]),
     "cg_mcmc_accepts": (C.c_int, [C.c_void_p, c_lp]),
+    "cg_mcmc_accept_rate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.POINTER(C.c_double)]),
     "cg_wrap": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "cg_ewald": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cg_grad_laplacian": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -2,10 +2,12 @@
 (src/MCMC.py:39, src/VMC.py:46-53,63,72, main.py:280).  One process per GPU.
 
   NullComm        world size 1 (identity)
-  RcclComm        RCCL all-reduce over xGMI through the C-ABI (cg_allreduce_mean); the 128-byte unique id is
-                  exchanged through torch.distributed's store/broadcast (plumbing only)
-  TorchDistComm   torch.distributed all_reduce on host tensors (gloo) -- used by the CPU tests of the
-                  multi-process host logic
+  RcclComm        RCCL all-reduce over xGMI through the C-ABI (cg_allreduce_mean).  The 128-byte unique id travels from rank 0
+                  to the others in one TCP exchange on MASTER_ADDR : MASTER_PORT + 1 (tcp_broadcast_bytes); barrier and maxima
+                  go through the same all-reduce.  Nothing here imports torch: the reference needs nothing but its array
+                  library for the collectives (src/utils.py:4-8, main.py:214-239) and neither does this -- a launcher such as
+                  torch.distributed.run only provides RANK / WORLD_SIZE / MASTER_* in the environment.
+(the gloo communicator of the multi-process CPU tests lives in tests/torch_comm.py)
 """
 import ctypes as C
 import os
@@ -22,40 +24,15 @@ class NullComm:
         """in-place mean over the ranks of a device-resident array (or of `count` elements from `index`): nothing to do"""
         return a
 
-    def close(self):
+    def accept_rate(self, engine, denom):
+        """accepted moves of the engine's last chain / denom (src/MCMC.py:37-39)"""
+        return engine.mcmc_accepts() / float(denom) if denom else 0.0
+
+    def pmax(self, v):
+        return float(v)
+
+    def barrier(self):
         pass
-
-
-class TorchDistComm:
-    def __init__(self, device=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.device = device          # None: host tensors (gloo); "cuda": nccl(=RCCL) through torch
-
-    def pmean(self, a):
-        import torch
-        t = torch.from_numpy(np.array(a, dtype=np.float64, ndmin=1, copy=True))
-        if self.device is not None:
-            t = t.to(self.device)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-            out = (t / self.world).cpu().numpy()
-            return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-        out = (t / self.world).numpy()
-        return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
-
-    def pmean_d(self, a, count=None, index=0):
-        """array handles of the CPU test engine are numpy arrays: all-reduce in place"""
-        if not isinstance(a, np.ndarray):
-            raise TypeError("TorchDistComm.pmean_d works on the numpy handles of the CPU test engine; device arrays of a GPU "
-                            "engine are reduced by RcclComm (got %s)" % type(a).__name__)
-        flat = a.reshape(-1)
-        if index < 0 or (count is not None and index + count > flat.size):
-            raise IndexError("pmean_d: [%d, %d) outside an array of %d elements" % (index, index + (count or 0), flat.size))
-        n = flat.size - index if count is None else count
-        flat[index:index + n] = self.pmean(flat[index:index + n])
-        return a
 
     def close(self):
         pass
@@ -75,7 +52,7 @@ class RcclComm:
                 raw = bytes(uid.raw)
             else:
                 if exchange is None:
-                    exchange = _torch_broadcast_bytes
+                    exchange = lambda payload: tcp_broadcast_bytes(payload, rank, world)
                 raw = exchange(bytes(uid.raw) if rank == 0 else None)
             uid = (C.c_char * 128).from_buffer_copy(raw)
         else:
@@ -110,6 +87,18 @@ class RcclComm:
         a.version += 1
         return a
 
+    def accept_rate(self, engine, denom):
+        """src/MCMC.py:37-39: the rate is formed from the device counter and averaged over the ranks on the device (8 bytes come back)"""
+        return engine.mcmc_accept_rate(denom, self._h) if denom else 0.0
+
+    def pmax(self, v):
+        """maximum of a host scalar over the ranks (e.g. the elapsed time of a benchmark)"""
+        return float(np.max(allgather(self, np.array([float(v)]))))
+
+    def barrier(self):
+        """every rank has reached this point and its stream is drained: a one-element all-reduce"""
+        self.pmean(0.0)
+
     def close(self):
         if self._h is not None:
             from ._lib import lib
@@ -117,16 +106,49 @@ class RcclComm:
             self._h = None
 
 
-def _torch_broadcast_bytes(payload):
-    import torch
-    import torch.distributed as dist
-    t = torch.zeros(128, dtype=torch.uint8)
-    if dist.get_rank() == 0:
-        t = torch.tensor(list(payload), dtype=torch.uint8)
-    if dist.get_backend() == "nccl":
-        t = t.cuda()
-    dist.broadcast(t, src=0)
-    return bytes(t.cpu().tolist())
+def tcp_broadcast_bytes(payload, rank, world, addr=None, port=None, timeout=300.0):
+    """Rank 0 hands `payload` (the 128-byte RCCL id) to the other ranks of the job: it listens on port MASTER_PORT + 1 (or
+    CG_RDZV_PORT; MASTER_PORT itself belongs to the launcher's own store under torch.distributed.run) and sends the bytes to each
+    of the world - 1 peers that connect; the peers retry until it is up.  Returns the payload on every rank."""
+    import socket, time
+    if world == 1:
+        return payload
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ.get("CG_RDZV_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + 1)
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        try:
+            srv.bind(("", port))
+        except OSError as e:
+            raise RuntimeError("coulombgas_amd.comm: cannot listen on port %d for the RCCL id exchange (%s); set CG_RDZV_PORT" % (port, e))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        try:
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(payload)
+        finally:
+            srv.close()
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=10.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise RuntimeError("coulombgas_amd.comm: rank %d could not reach rank 0 at %s:%d" % (rank, addr, port))
+            time.sleep(0.05)
+    buf = b""
+    with s:
+        while len(buf) < len(payload or b"") or (payload is None and len(buf) < 128):
+            chunk = s.recv(128 - len(buf))
+            if not chunk:
+                raise RuntimeError("coulombgas_amd.comm: rank 0 closed the id exchange early (%d of 128 bytes)" % len(buf))
+            buf += chunk
+    return buf
 
 
 def allgather(comm, a):

@@ -305,6 +305,7 @@ int cg_create(cg_ctx** out, int device, int n, int dim, int depth, int spsize, i
     std::vector<double> spk((size_t)M * dim);
     for (size_t i = 0; i < spk.size(); ++i) spk[i] = sp_indices[i] * (2.0 * CG_PI / L);     // src/slater.py:14
     if ((e = hipMemcpy(c->d_spk, spk.data(), sizeof(double) * spk.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail("hipMemcpy orbitals", e);
+    if ((e = hipMalloc((void**)&c->d_rate, sizeof(double))) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(c->d_accept, 0, sizeof(unsigned long long))) != hipSuccess) return fail("hipMemset", e);
     *out = c;
     return CG_OK;
@@ -327,6 +328,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->d_G) (void)hipFree(c->d_G);
     if (c->d_gk) (void)hipFree(c->d_gk);
     if (c->d_accept) (void)hipFree(c->d_accept);
+    if (c->d_rate) (void)hipFree(c->d_rate);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->ev_b) (void)hipEventDestroy(c->ev_b);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -626,11 +628,15 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
     // workgroup shape: as many waves per CU as the 160 KB of LDS allow with the weights staged once per workgroup (the kernel is
     // latency-bound: one wave per SIMD left it at 8.0 ms for B = 8192, n = 13)
     int waves = 0, plds = 1;
+    // (workgroups of <= 4 waves of the shipped architecture run the register-accumulating kernel, which is pinned to one wave per SIMD:
+    // never more than 4 waves per CU whatever the LDS would allow -- the estimates below count that)
+    const bool reg_possible = cg_env_int("CG_VAN_GRAD_REG", 1) > 0 && m.ms == 16 && m.hs == 32 && m.nl == 2 && m.nh == 4 && m.dim * m.ms <= 64 && m.M <= 256;
+    auto cap = [&](int w, int per_cu) { return (reg_possible && w <= 4) ? std::min(per_cu, 4) : per_cu; };
     { int best = 0;
       for (int w = 1; w <= 8; ++w) {
           const size_t need = pbytes + w * wbytes;
           if (need > 160 * 1024) break;
-          const int per_cu = w * (int)((160 * 1024) / need);
+          const int per_cu = cap(w, w * (int)((160 * 1024) / need));
           if (per_cu > best) { best = per_cu; waves = w; }
       } }
     if (waves == 0) { plds = 0; waves = 4; while (waves > 1 && waves * wbytes > 160 * 1024) --waves; }
@@ -640,8 +646,8 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
     if (plds) {
         int w0 = 1; while (w0 < 8 && (size_t)(w0 + 1) * wbytes <= 160 * 1024) ++w0;
         int best0 = 0, wsel = 1;
-        for (int w = 1; w <= w0; ++w) { const int per_cu = w * (int)((160 * 1024) / (w * wbytes)); if (per_cu > best0 || (per_cu == best0 && w <= 2)) { best0 = per_cu; wsel = w; } }
-        const int per_cu1 = waves * (int)((160 * 1024) / (pbytes + waves * wbytes));
+        for (int w = 1; w <= w0; ++w) { const int per_cu = cap(w, w * (int)((160 * 1024) / (w * wbytes))); if (per_cu > best0 || (per_cu == best0 && w <= 2)) { best0 = per_cu; wsel = w; } }
+        const int per_cu1 = cap(waves, waves * (int)((160 * 1024) / (pbytes + waves * wbytes)));
         const int rounds1 = (B + c->cu_count * per_cu1 - 1) / (c->cu_count * per_cu1), rounds0 = (B + c->cu_count * best0 - 1) / (c->cu_count * best0);
         if (rounds0 * 7 <= rounds1 * 5) { plds = 0; waves = wsel; }
     }

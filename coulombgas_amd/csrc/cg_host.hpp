@@ -73,6 +73,7 @@ struct cg_ctx {
     CgGenWs gw;
     CgGenWs gwv;      // the same + the reverse-pass arena of the theta-VJP
     unsigned long long* d_accept = nullptr;
+    double* d_rate = nullptr;             // device scalar of cg_mcmc_accept_rate
     // staging arena for host-pointer mode + internal workspaces
     std::vector<Chunk> chunks;
     size_t cur = 0, off = 0;

@@ -246,17 +246,33 @@ static int run_vjp(cg_ctx* c, const char* fn, const double* x, const int32_t* si
         // the second-generation kernel (cg_score.hpp) where the system fits its LDS plan, otherwise by the first-generation one
         // (cg_derivs.hpp); the weighted sum over the batch is then the sliced GEMV over the score matrix
         const CgDev m = make_dev(c);
+        auto scores_of = [&](const double* xs, const int* ss, int nb, double* out) -> int {
+            int r;
+            if ((r = cg_derivs_a_scores(c, m, xs, ss, nb, out)) < 0) return r;
+            if (r == 0 && (r = cg_derivs_b_scores(c, m, xs, ss, nb, out)) < 0) return r;
+            if (r == 0 && (r = cg_derivs_a_param_vjp(c, m, xs, ss, nb, out)) < 0) return r;
+            if (r == 0 && (r = cg_derivs_b_param_vjp(c, m, xs, ss, nb, out)) < 0) return r;
+            if (r != 1) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
+            return CG_OK;
+        };
         double* sc = (double*)asc.dev;
-        if (!sc) {
-            sc = (double*)arena_take(c, asc.bytes);
-            if (!sc) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
+        if (sc) {
+            if ((rc = scores_of((const double*)ax.dev, (const int*)as.dev, B, sc))) return rc;
+            if (g_theta && (rc = score_reduce(c, sc, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
+        } else {
+            // plain theta-VJP (no score output, no resident scores wanted): the batch in slices through a bounded temporary -- the
+            // arena only ever grows, and a (B, P, 2) score matrix (140 MB at n = 13, B = 8192) would stay in the context's footprint
+            const int Bc = std::min(B, 1024);
+            sc = (double*)arena_take(c, sizeof(double) * (size_t)Bc * P * 2);
+            double* gt = (double*)arena_take(c, sizeof(double) * (size_t)P);
+            if (!sc || !gt) CG_FAIL(c, CG_ERR_HIP, "%s: workspace allocation failed", fn);
+            for (int b0 = 0; b0 < B; b0 += Bc) {
+                const int nb = std::min(Bc, B - b0);
+                if ((rc = scores_of((const double*)ax.dev + (size_t)b0 * N, (const int*)as.dev + (size_t)b0 * n, nb, sc))) return rc;
+                if ((rc = score_reduce(c, sc, (const double*)awr.dev + b0, (const double*)awi.dev + b0, nb, P, b0 ? gt : (double*)ag.dev))) return rc;
+                if (b0 && (rc = cg_axpby(c, 1.0, gt, 1.0, (double*)ag.dev, (size_t)P))) return rc;
+            }
         }
-        if ((rc = cg_derivs_a_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-        if (rc == 0 && (rc = cg_derivs_b_scores(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-        if (rc == 0 && (rc = cg_derivs_a_param_vjp(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-        if (rc == 0 && (rc = cg_derivs_b_param_vjp(c, m, (const double*)ax.dev, (const int*)as.dev, B, sc)) < 0) return rc;
-        if (rc != 1) CG_FAIL(c, CG_ERR_UNSUPPORTED, "%s: configuration not instantiated", fn);
-        if (g_theta && (rc = score_reduce(c, sc, (const double*)awr.dev, (const double*)awi.dev, B, P, (double*)ag.dev))) return rc;
     } else {              // any depth / widths: dual-number reverse passes of the primal flow (cg_generic.hpp)
         const int grid = std::min(B, c->cu_count * 2 * CG_DERIV_WAVES);
         double* partial = g_theta ? (double*)arena_take(c, sizeof(double) * (size_t)grid * P) : nullptr;

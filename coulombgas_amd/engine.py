@@ -440,8 +440,9 @@ class Engine:
     def to_host_slice(self, a, start, count):
         return a.numpy(start, count)
 
-    def mcmc_d(self, x_d, sidx_d, mc_steps, mc_stddev, seed=0, walker_offset=0, noise=None, unif=None):
-        """the chain of src/MCMC.py:22-39 in place on x_d; returns the number of accepted moves (8-byte read-back)"""
+    def mcmc_d(self, x_d, sidx_d, mc_steps, mc_stddev, seed=0, walker_offset=0, noise=None, unif=None, count=True):
+        """the chain of src/MCMC.py:22-39 in place on x_d; returns the number of accepted moves (8-byte read-back; count=False: None,
+        the caller takes the rate from mcmc_accept_rate instead)"""
         B = x_d.shape[0]
         nz = un = None
         if noise is not None:
@@ -450,7 +451,7 @@ class Engine:
         self._dev_call(lib().cg_mcmc, x_d.ptr, sidx_d.ptr, int(B), int(mc_steps), float(mc_stddev), int(seed), int(walker_offset),
                        nz.ptr if nz is not None else None, un.ptr if un is not None else None, None, None)
         x_d.version += 1
-        return self.mcmc_accepts()
+        return self.mcmc_accepts() if count else None
 
     def wrap_d(self, x_d):
         self._dev_call(lib().cg_wrap, x_d.ptr, int(x_d.shape[0]))
@@ -665,6 +666,12 @@ class Engine:
         v = C.c_int64(0)
         check(lib().cg_mcmc_accepts(self._ctx, C.byref(v)), self._ctx)
         return int(v.value)
+
+    def mcmc_accept_rate(self, denom, comm_handle=None):
+        """accepted moves of the last chain / denom, averaged over the ranks of an RCCL communicator on the device (src/MCMC.py:39)"""
+        v = C.c_double(0.0)
+        check(lib().cg_mcmc_accept_rate(self._ctx, comm_handle, float(denom), C.byref(v)), self._ctx)
+        return float(v.value)
 
     def logp_dev(self, x_buf, sidx_buf, B, out_buf):
         assert self._mode == _lib.CG_PTR_DEVICE

@@ -33,10 +33,15 @@ def mcmc(logp_fn, x_init, key, mc_steps, mc_stddev=0.02, noise=None, unif=None, 
         x_d = eng.asdevice(np.asarray(x_init, dtype=np.float64).reshape((batch,) + tuple(np.shape(x_init)[-2:])), "x_chain")
     si = logp_fn.state_indices
     s_d = si if hasattr(si, "ptr") else eng.asdevice(np.asarray(si).reshape(batch, -1), "sidx", np.int32)
-    nacc = eng.mcmc_d(x_d, s_d, mc_steps, mc_stddev, seed=_seed_of(key), walker_offset=walker_offset, noise=noise, unif=unif)
+    cm = comm or get_comm()
+    dev_rate = hasattr(cm, "accept_rate") and hasattr(eng, "mcmc_accept_rate")
+    nacc = eng.mcmc_d(x_d, s_d, mc_steps, mc_stddev, seed=_seed_of(key), walker_offset=walker_offset, noise=noise, unif=unif,
+                      **({"count": False} if dev_rate else {}))
     if wrap_L is not None:
         eng.wrap_d(x_d)
-    accept_rate = nacc / (mc_steps * batch) if mc_steps * batch else 0.0
-    accept_rate = (comm or get_comm()).pmean(accept_rate)
+    if dev_rate:      # src/MCMC.py:37-39: the rate is formed from the device counter and averaged over the ranks there
+        accept_rate = cm.accept_rate(eng, mc_steps * batch)
+    else:
+        accept_rate = cm.pmean(nacc / (mc_steps * batch) if mc_steps * batch else 0.0)
     x = x_d if on_device else eng.to_host(x_d).reshape(lead + tuple(np.shape(x_init)[-2:]))
     return x, accept_rate

@@ -126,7 +126,9 @@ int cg_grad_laplacian(cg_ctx* ctx, const double* x, const int32_t* state_idx, in
                       const double* v, double* grad, double* lap);
 
 /* g_theta (P) = sum_b [ w_re[b] * d/dtheta Re log Psi_b + w_im[b] * d/dtheta Im log Psi_b ]:
- * the vector-Jacobian product jax.jacrev(quantum_lossfn) needs (src/VMC.py:69-76, main.py:278). */
+ * the vector-Jacobian product jax.jacrev(quantum_lossfn) needs (src/VMC.py:69-76, main.py:278).
+ * Workspace: per-sample scores of at most 1024 walkers at a time (16 P bytes each) plus the kernels' own slots; the
+ * (B, P, 2) score matrix is only materialised by cg_quantum_score / cg_scores_compute. */
 int cg_param_vjp(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B,
                  const double* w_re, const double* w_im, double* g_theta);
 /* per-sample scores S (B,P,2) complex = make_quantum_score(logpsi)  (src/logpsi.py:183-203) */
@@ -226,6 +228,10 @@ int cg_comm_create(cg_comm** out, cg_ctx* ctx, int rank, int world, const void* 
 void cg_comm_destroy(cg_comm* comm);
 /* in-place mean over ranks of `count` doubles (DEVICE pointer on the ctx's device) */
 int cg_allreduce_mean(cg_comm* comm, double* buf_dev, size_t count);
+/* acceptance rate of the most recent cg_mcmc on ctx: accepted moves / denom (= mc_steps x batch), formed on the device and, with a
+ * communicator, averaged over its ranks there -- the lax.pmean of src/MCMC.py:39 without staging the operand through the host.
+ * comm may be NULL (this rank alone).  rate: HOST pointer.  Synchronises the stream. */
+int cg_mcmc_accept_rate(cg_ctx* ctx, cg_comm* comm, double denom, double* rate);
 
 #ifdef __cplusplus
 }

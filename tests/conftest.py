@@ -11,27 +11,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# bench.py's N > 1 branch (torch.distributed rendezvous, RCCL communicator from the library, device-side accept-rate pmean) on a
-# one-GPU box: launched ONCE, at session start -- before this process has touched the GPU -- as a child under torch.distributed.run
-# with one rank and CG_FORCE_DIST=1; tests/test_gpu_rccl.py asserts on what it printed.
+# bench.py's N > 1 branch (RANK / WORLD_SIZE / MASTER_* from the environment, the library's own RCCL communicator with its TCP id
+# exchange, device-side accept-rate pmean, barrier and MAX through cg_allreduce_mean) on a one-GPU box: launched ONCE -- before this
+# process has touched the GPU -- as a plain `python bench.py` child with world 1 and CG_FORCE_DIST=1, and only when the test that
+# reads its output (tests/test_gpu_rccl.py::test_bench_distributed_branch_without_torch_distributed) has been collected.
 BENCH_DIST = {}
 
 
-def pytest_sessionstart(session):
-    expr = session.config.getoption("markexpr", default="") or ""
-    if "gpu" not in expr or "not gpu" in expr:
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def pytest_collection_finish(session):
+    if not any(it.name.startswith("test_bench_distributed_branch") for it in session.items) or session.config.getoption("collectonly", False):
         return
-    try:
-        import torch
-        if torch.cuda.device_count() < 1:          # (counting devices does not initialise the GPU)
-            return
-    except ImportError:
+    if not os.path.exists("/dev/kfd"):              # no AMD GPU driver node: not a GPU box
         return
     import subprocess
-    env = dict(os.environ, CG_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    port = 29700 + os.getpid() % 200
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+    env = dict(os.environ, CG_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-energy-check", "--no-update-extras"]
     try:
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)

@@ -15,7 +15,8 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     import coulombgas_amd as cg
     import coulombgas_amd.flow as fl
-    from coulombgas_amd.comm import TorchDistComm, set_comm
+    from coulombgas_amd.comm import set_comm
+    from tests.torch_comm import TorchDistComm
     from tests import emul_engine
     from tests.test_host_logic import _problem, build_loss
 

@@ -49,3 +49,32 @@ def test_two_ranks_match_single_process(tmp_path, monkeypatch):
     assert np.abs(r0["cf"] - cf).max() < 1e-12 * np.abs(cf).max()
     assert np.abs(r0["qf"] - qf).max() < 1e-10 * np.abs(qf).max() and np.abs(r0["qm"] - qm).max() < 1e-10 * np.abs(qm).max()
 
+
+
+def _rdzv_rank(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from coulombgas_amd.comm import tcp_broadcast_bytes
+    payload = bytes(range(128)) if rank == 0 else None
+    q.put((rank, tcp_broadcast_bytes(payload, rank, world, timeout=60.0)))
+
+
+@pytest.mark.timeout(120)
+def test_rccl_id_exchange_over_tcp_world3():
+    """the rendezvous of coulombgas_amd.comm.RcclComm (rank 0 serves the 128-byte id on MASTER_PORT + 1, the peers retry until it is
+    up) between three processes on the CPU: every rank ends with rank 0's bytes; no torch anywhere"""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_rdzv_rank, args=(r, world, port, q)) for r in (2, 1, 0)]      # the peers start first
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=100) for _ in range(world))
+    for p in procs:
+        p.join(30); assert p.exitcode == 0
+    assert all(got[r] == bytes(range(128)) for r in range(world))
+    import coulombgas_amd.comm as cm
+    assert "import torch" not in open(cm.__file__).read()

@@ -79,14 +79,36 @@ def test_training_with_a_world1_rccl_communicator_equals_the_null_communicator()
     assert all(np.isfinite([float(v) for v in r.split()]).all() for r in out["rccl"][0])
 
 
-def test_bench_distributed_branch_under_torch_distributed_run(request):
-    """bench.py's N > 1 code path, launched at session start (tests/conftest.py) as `python -m torch.distributed.run
-    --nproc-per-node 1 bench.py --gpus 1` with CG_FORCE_DIST=1: NCCL(=RCCL) process group through torch for the rendezvous, the
-    library's own communicator for the data path."""
+def test_bench_distributed_branch_without_torch_distributed(request):
+    """bench.py's N > 1 code path, launched once per session (tests/conftest.py) as plain `python bench.py --gpus 1` with
+    RANK / WORLD_SIZE / MASTER_* in the environment and CG_FORCE_DIST=1: the library's own RCCL communicator (id exchange of
+    coulombgas_amd.comm, no torch.distributed), the accept rate reduced on the device, barrier / MAX through cg_allreduce_mean."""
     r = getattr(request.config, "_cg_bench_dist", None)
-    assert r, "the session-start launch did not run (pytest -m gpu on a GPU box)"
+    assert r, "the session launch did not run (pytest -m gpu on a GPU box)"
     assert r["rc"] == 0, r["out"][-2000:] + r["err"]
     line = [l for l in r["out"].splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["comm"] == "rccl via cg_allreduce_mean" and j["n_gpus"] == 1 and j["finite"] and j["value"] > 1e6
     assert 0.3 < j["accept_rate"] < 0.95
+
+
+def test_accept_rate_on_the_device_equals_the_host_count():
+    """cg_mcmc_accept_rate (count / denom formed on the device, all-reduced there by a world-1 communicator) against the counter
+    read back by cg_mcmc_accepts, and through coulombgas_amd.mcmc with RcclComm / NullComm"""
+    import coulombgas_amd as cg
+    from coulombgas_amd.comm import RcclComm, NullComm
+    flow, eng, sp, L = _engine()
+    n, dim, B, steps = 13, 2, 512, 7
+    rng = np.random.default_rng(5)
+    theta = flow.ravel(flow.init(3, np.zeros((n, dim))), dim)
+    logp = cg.make_logp(cg.make_logpsi(flow, sp, L))
+    x = rng.uniform(0, L, (B, n, dim)); sidx = np.tile(np.arange(sp.shape[0] - n, sp.shape[0], dtype=np.int32), (B, 1))
+    comm = RcclComm(eng, 0, 1)
+    rates = []
+    for cm in (NullComm(), comm):
+        _, rate = cg.mcmc(logp.bind(flow.unravel(theta, dim), sidx), x, 123, steps, 0.1, comm=cm)
+        rates.append(rate)
+        assert rate == eng.mcmc_accepts() / float(steps * B)
+    assert rates[0] == rates[1] and 0.2 < rates[0] < 1.0
+    assert comm.pmax(3.25) == 3.25
+    comm.barrier(); comm.close()
