@@ -89,7 +89,13 @@ def cpu_baseline(n, dim, L, sp, theta, sidx, x, mc_steps, stddev, budget_s=24.0,
     B2 = int(min(x.shape[0], max(cores, rate * per_run / mc_steps // cores * cores))); s2 = mc_steps
     r2, t2 = median_rate(B2, s2)
     fl = DENSE_AD_FLOPS_PER_WALKER_STEP.get(n)
+    try:                                                 # SURVEY 8(d)'s optional second baseline needs JAX on the box
+        import importlib.util
+        jax_here = importlib.util.find_spec("jax") is not None
+    except Exception:                                    # noqa: BLE001
+        jax_here = False
     return {"value": r2, "unit": "walker-steps/s", "cores": int(cores), "kind": "port",
+            "jax_on_this_box": jax_here, "jax_note": "the reference's JAX path cannot be timed: JAX / Haiku / Optax are not installed (probed at run time)" if not jax_here else "JAX importable: not used (the reference itself is not on this box)",
             "sample": "median of %d runs: %d walkers x %d mc_steps of the timed workload (n=%d), %.2f s per run" % (reps, B2, s2, n, t2[len(t2) // 2]),
             "config1_shape": {"value": r1, "sample": "median of %d runs: B=%d x %d mc_steps, %.2f s per run" % (reps, B1, s1, t1[len(t1) // 2])},
             "gflops_per_core": (r2 * fl / cores / 1e9) if fl else None,
@@ -285,8 +291,8 @@ def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # 100 x 11 ms: long enough for an outside GPU-activity sampler to see the timed region
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=13)
     ap.add_argument("--batch", type=int, default=8192, help="walkers per GPU")
     ap.add_argument("--mc_steps", type=int, default=50)

@@ -47,8 +47,8 @@ _warned_indefinite = [False]
 
 def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, center=None):
     """src/sr.py:38-45 / 102-117: (F + damping I)^-1 g, scaled by -min(sqrt(max_norm / g.F^-1 g), 1).  With an engine the
-    damped solve runs on the GPU (cg_spd_solve: centring, shift, blocked Cholesky, both triangular solves); host LAPACK for
-    small systems (P < 512).  The ONLY device outcome that is handled here is CG_ERR_STATE = "the shifted matrix is not
+    damped solve runs on the GPU at every size (cg_spd_solve: centring, shift, blocked Cholesky, both triangular solves); host
+    LAPACK only for host matrices handed in WITHOUT an engine (a score function of the caller's own).  The ONLY device outcome that is handled here is CG_ERR_STATE = "the shifted matrix is not
     positive definite" (round-off on a nearly singular Fisher matrix): the reference's jax.scipy.linalg.solve is a general
     LU solve and would still return a result, so that case goes to the host's symmetric-indefinite solver, once with a
     warning.  Every other device error propagates.  center: complex score mean m; the matrix solved is
@@ -57,7 +57,7 @@ def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, cente
     from ._lib import CoulombGasError, CG_ERR_STATE
     upd = None
     on_device = not isinstance(fisher, np.ndarray) and hasattr(fisher, "ptr")
-    if on_device or (engine is not None and hasattr(engine, "spd_solve") and fisher.shape[0] >= 512):
+    if on_device or (engine is not None and hasattr(engine, "spd_solve")):
         try:
             if on_device:          # the matrix never leaves HBM (the solver factors a device-side copy)
                 upd = fisher.eng.spd_solve_d(fisher.base, grads_raveled, damping, center, index=fisher.index, P=fisher.shape[0])
