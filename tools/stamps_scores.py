@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: cycles per phase of k_scores (s_memtime stamps, -DCG_STAMPS build; tools/devbuild_diag.sh).
+"""Diagnostic: cycles per phase of k_scores (s_memtime stamps, -DCG_STAMPS build; python -m coulombgas_amd.build --diag).
    COULOMBGAS_HIP_LIB=coulombgas_amd/lib/diag/libcg_stamps.so python tools/stamps_scores.py [n] [B]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
