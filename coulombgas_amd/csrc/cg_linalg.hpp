@@ -360,16 +360,25 @@ __device__ __forceinline__ unsigned cg_wave_max_u32(unsigned v) {
 // and step, no matrix traffic at all (the in-place LDS version above moves the whole matrix through LDS every column: 1.1 ms per
 // walker at N = 114).  In-place bookkeeping: slot k of the tile matrix ends as column p_k of the inverse of the row-permuted system:
 //     A^-1[k][p_j] = S[p_k][j]        (scattered straight to the destination).
-// A, Ainv: any memory; sc: LDS, >= 4 N + 32 + N doubles (complex: 8 N + 32 + N).  Needs ceil(N/TR) ceil(N/TC) <= nthr, ceil(N/TR) <= 16.
+// A, Ainv: any memory; sc: LDS, >= 5 N + 64 doubles (what the callers reserve; exact need below).  Needs ceil(N/TR) ceil(N/TC) <= nthr, ceil(N/TR) <= 16.
 // ------------------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
+// Round 4: what a column cost was latency, not arithmetic (6.5 k cycles per column at N = 114, tools/lu_bench/tile_inv_bench.hip): the
+// candidates were read back one by one (a dependent LDS read + compare + branch per tile row) and the pivot row / column went through
+// single, predicated 8-byte accesses.  Now every thread fetches the <= 16 candidates with 16-byte reads in one round trip and picks the
+// winner branch-free, and the pivot row / column buffers are padded to whole tiles so that they are written and read with unpredicated
+// 16-byte accesses.  sc: LDS, >= 4 NP + 32 + N doubles with NP = N rounded up to 8 (complex: 8 NP + 32 + N, NP = N rounded up to 4), 16-byte aligned.
 template <int TR, int TC>
 __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef int i4_t __attribute__((ext_vector_type(4)));
+    static_assert(TR % 2 == 0 && TC % 2 == 0, "16-byte accesses");
     const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
-    const int tr = b.tid / tcn, tc = b.tid - tr * tcn;
     const bool act = b.tid < trn * tcn;
+    const int tr = act ? b.tid / tcn : 0, tc = act ? b.tid - tr * tcn : 0;
     const int i0 = tr * TR, j0 = tc * TC;
-    double* rowb = sc; double* colb = sc + 2 * N; double* cv = sc + 4 * N; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    const int NP = (N + 7) & ~7;
+    double* rowb = sc; double* colb = sc + 2 * NP; double* cv = sc + 4 * NP; int* ci = (int*)(cv + 18); int* piv = (int*)(cv + 32); int* kinv = piv + N;
     double a[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
@@ -378,8 +387,8 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
     unsigned used = 0;
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;          // rows beyond the matrix never pivot
-    // columns in groups of TC so that the pivot column's index inside its owners' tiles is a compile-time constant (the dynamic
-    // version extracted it with TR x TC selects, twice per column, and tested every element against row p / column k)
+    if (b.tid >= trn && b.tid < 16) { cv[b.tid] = -3.0; ci[b.tid] = 0x7fffffff; }   // candidate slots nobody posts to never win
+    // columns in groups of TC so that the pivot column's index inside its owners' tiles is a compile-time constant
     for (int kc = 0; kc < N; kc += TC) {
         const bool mycol = act && j0 == kc;
 #pragma unroll
@@ -399,34 +408,54 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
                     cv[tr] = best; ci[tr] = bi;
                 }
                 b.sync();
-                double best = cv[0]; int p = ci[0];
-#pragma unroll 4
-                for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+                int p;
+                {   // the largest candidate, the first one among equals (= the smallest row: tile rows post in order)
+                    d2_t c2[8]; i4_t q4[4];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) c2[t] = ((const d2_t*)cv)[t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) q4[t] = ((const i4_t*)ci)[t];
+                    double best = c2[0][0]; p = q4[0][0];
+#pragma unroll
+                    for (int t = 1; t < 16; ++t) { const double v = c2[t >> 1][t & 1]; const bool take = v > best; best = take ? v : best; p = take ? q4[t >> 2][t & 3] : p; }
+                }
                 const bool myrow = act && p >= i0 && p < i0 + TR;
                 const int ip = p - i0;
+                // (every thread of the pivot's tile row has the same ip: made a scalar, the row is picked by uniform branches -- a register
+                // array cannot be indexed by a lane value, and the select chains it took were ~120 instructions on the wave everybody waits for)
                 if (myrow) {
+                    const int ips = __builtin_amdgcn_readfirstlane(ip);     // (inside the branch: the first ACTIVE lane is one of the tile row)
+                    double v[TC];
 #pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) {
-                        double v = 0.0;
+                    for (int jj = 0; jj < TC; ++jj) v[jj] = 0.0;
 #pragma unroll
-                        for (int ii = 0; ii < TR; ++ii) v = ii == ip ? a[ii][jj] : v;
-                        if (j0 + jj < N) rowb[buf * N + j0 + jj] = v;
-                        if (mycol && jj == jk) cv[16 + buf] = 1.0 / v;   // the owner of the pivot publishes its reciprocal
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ips == ii) {
+#pragma unroll
+                            for (int jj = 0; jj < TC; ++jj) v[jj] = a[ii][jj];
+                        }
+                    if (mycol) {                                             // the owner of the pivot publishes its reciprocal
+                        const double pvv = v[jk], r0 = __builtin_amdgcn_rcp(pvv);
+                        double r1 = fma(r0, fma(-pvv, r0, 1.0), r0);
+                        r1 = fma(r1, fma(-pvv, r1, 1.0), r1);
+                        cv[16 + buf] = fabs(pvv) > 0.0 ? r1 : r0;
                     }
+#pragma unroll
+                    for (int jj = 0; jj < TC; jj += 2) *(d2_t*)(rowb + buf * NP + j0 + jj) = d2_t{v[jj], v[jj + 1]};     // (padding included)
                     used |= 1u << ip;
                 }
                 if (mycol) {
 #pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) if (i0 + ii < N) colb[buf * N + i0 + ii] = a[ii][jk];
+                    for (int ii = 0; ii < TR; ii += 2) *(d2_t*)(colb + buf * NP + i0 + ii) = d2_t{a[ii][jk], a[ii + 1][jk]};
                 }
                 if (b.tid == 0) piv[k] = p;
                 b.sync();
                 const double rinv = cv[16 + buf];
                 double rj[TC], cI[TR];
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj) rj[jj] = (j0 + jj < N ? rowb[buf * N + j0 + jj] : 0.0) * rinv;
+                for (int jj = 0; jj < TC; jj += 2) { const d2_t t = *(const d2_t*)(rowb + buf * NP + j0 + jj); rj[jj] = t[0] * rinv; rj[jj + 1] = t[1] * rinv; }
 #pragma unroll
-                for (int ii = 0; ii < TR; ++ii) cI[ii] = i0 + ii < N ? colb[buf * N + i0 + ii] : 0.0;
+                for (int ii = 0; ii < TR; ii += 2) { const d2_t t = *(const d2_t*)(colb + buf * NP + i0 + ii); cI[ii] = t[0]; cI[ii + 1] = t[1]; }
 #pragma unroll
                 for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
@@ -436,12 +465,13 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
                     for (int ii = 0; ii < TR; ++ii) a[ii][jk] = -cI[ii] * rinv;
                 }
                 if (myrow) {
+                    const int ips = __builtin_amdgcn_readfirstlane(ip);
 #pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) {
-                        const bool isp = ii == ip;
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ips == ii) {
 #pragma unroll
-                        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = isp ? ((mycol && jj == jk) ? rinv : rj[jj]) : a[ii][jj];
-                    }
+                            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (mycol && jj == jk) ? rinv : rj[jj];
+                        }
                 }
             }
         }
@@ -461,11 +491,14 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
 // complex version: interleaved (re, im), lda / ldi in complex elements
 template <int TR, int TC>
 __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    typedef int i4_t __attribute__((ext_vector_type(4)));
     const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
-    const int tr = b.tid / tcn, tc = b.tid - tr * tcn;
     const bool act = b.tid < trn * tcn;
+    const int tr = act ? b.tid / tcn : 0, tc = act ? b.tid - tr * tcn : 0;
     const int i0 = tr * TR, j0 = tc * TC;
-    double* rowb = sc; double* colb = sc + 4 * N; double* cv = sc + 8 * N; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    const int NP = (N + 3) & ~3;
+    double* rowb = sc; double* colb = sc + 4 * NP; double* cv = sc + 8 * NP; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
     double ar[TR][TC], ai[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
@@ -478,6 +511,7 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
     unsigned used = 0;
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;
+    if (b.tid >= trn && b.tid < 16) { cv[b.tid] = -3.0; ci[b.tid] = 0x7fffffff; }
     for (int kc = 0; kc < N; kc += TC) {
         const bool mycol = act && j0 == kc;
 #pragma unroll
@@ -497,35 +531,48 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
                     cv[tr] = best; ci[tr] = bi;
                 }
                 b.sync();
-                double best = cv[0]; int p = ci[0];
-#pragma unroll 4
-                for (int t = 1; t < trn; ++t) { const double v = cv[t]; const int q = ci[t]; const bool take = v > best || (v == best && q < p); best = take ? v : best; p = take ? q : p; }
+                int p;
+                {
+                    d2_t c2[8]; i4_t q4[4];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) c2[t] = ((const d2_t*)cv)[t];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) q4[t] = ((const i4_t*)ci)[t];
+                    double best = c2[0][0]; p = q4[0][0];
+#pragma unroll
+                    for (int t = 1; t < 16; ++t) { const double v = c2[t >> 1][t & 1]; const bool take = v > best; best = take ? v : best; p = take ? q4[t >> 2][t & 3] : p; }
+                }
                 const bool myrow = act && p >= i0 && p < i0 + TR;
                 const int ip = p - i0;
                 if (myrow) {
+                    const int ips = __builtin_amdgcn_readfirstlane(ip);     // (see the real version)
+                    double vr[TC], vi[TC];
 #pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) {
-                        double vr = 0.0, vi = 0.0;
+                    for (int jj = 0; jj < TC; ++jj) { vr[jj] = 0.0; vi[jj] = 0.0; }
 #pragma unroll
-                        for (int ii = 0; ii < TR; ++ii) { vr = ii == ip ? ar[ii][jj] : vr; vi = ii == ip ? ai[ii][jj] : vi; }
-                        if (j0 + jj < N) { rowb[2 * (buf * N + j0 + jj)] = vr; rowb[2 * (buf * N + j0 + jj) + 1] = vi; }
-                        if (mycol && jj == jk) { const CgCplx r = cinv({vr, vi}); cv[16 + 2 * buf] = r.re; cv[17 + 2 * buf] = r.im; }
-                    }
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ips == ii) {
+#pragma unroll
+                            for (int jj = 0; jj < TC; ++jj) { vr[jj] = ar[ii][jj]; vi[jj] = ai[ii][jj]; }
+                        }
+#pragma unroll
+                    for (int jj = 0; jj < TC; ++jj) *(d2_t*)(rowb + 2 * (buf * NP + j0 + jj)) = d2_t{vr[jj], vi[jj]};           // (padding included)
+                    if (mycol) { const CgCplx r = cinv({vr[jk], vi[jk]}); *(d2_t*)(cv + 16 + 2 * buf) = d2_t{r.re, r.im}; }
                     used |= 1u << ip;
                 }
                 if (mycol) {
 #pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) if (i0 + ii < N) { colb[2 * (buf * N + i0 + ii)] = ar[ii][jk]; colb[2 * (buf * N + i0 + ii) + 1] = ai[ii][jk]; }
+                    for (int ii = 0; ii < TR; ++ii) *(d2_t*)(colb + 2 * (buf * NP + i0 + ii)) = d2_t{ar[ii][jk], ai[ii][jk]};
                 }
                 if (b.tid == 0) piv[k] = p;
                 b.sync();
-                const CgCplx rinv = {cv[16 + 2 * buf], cv[17 + 2 * buf]};
+                const d2_t rv = *(const d2_t*)(cv + 16 + 2 * buf);
+                const CgCplx rinv = {rv[0], rv[1]};
                 CgCplx rj[TC], cI[TR];
 #pragma unroll
-                for (int jj = 0; jj < TC; ++jj)
-                    rj[jj] = j0 + jj < N ? cmul({rowb[2 * (buf * N + j0 + jj)], rowb[2 * (buf * N + j0 + jj) + 1]}, rinv) : CgCplx{0.0, 0.0};
+                for (int jj = 0; jj < TC; ++jj) { const d2_t t = *(const d2_t*)(rowb + 2 * (buf * NP + j0 + jj)); rj[jj] = cmul({t[0], t[1]}, rinv); }
 #pragma unroll
-                for (int ii = 0; ii < TR; ++ii) cI[ii] = i0 + ii < N ? CgCplx{colb[2 * (buf * N + i0 + ii)], colb[2 * (buf * N + i0 + ii) + 1]} : CgCplx{0.0, 0.0};
+                for (int ii = 0; ii < TR; ++ii) { const d2_t t = *(const d2_t*)(colb + 2 * (buf * NP + i0 + ii)); cI[ii] = CgCplx{t[0], t[1]}; }
 #pragma unroll
                 for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
@@ -538,16 +585,17 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
                     for (int ii = 0; ii < TR; ++ii) { const CgCplx ck = cmul(cI[ii], rinv); ar[ii][jk] = -ck.re; ai[ii][jk] = -ck.im; }
                 }
                 if (myrow) {
+                    const int ips = __builtin_amdgcn_readfirstlane(ip);
 #pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) {
-                        const bool isp = ii == ip;
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ips == ii) {
 #pragma unroll
-                        for (int jj = 0; jj < TC; ++jj) {
-                            const bool pk = mycol && jj == jk;
-                            ar[ii][jj] = isp ? (pk ? rinv.re : rj[jj].re) : ar[ii][jj];
-                            ai[ii][jj] = isp ? (pk ? rinv.im : rj[jj].im) : ai[ii][jj];
+                            for (int jj = 0; jj < TC; ++jj) {
+                                const bool pk = mycol && jj == jk;
+                                ar[ii][jj] = pk ? rinv.re : rj[jj].re;
+                                ai[ii][jj] = pk ? rinv.im : rj[jj].im;
+                            }
                         }
-                    }
                 }
             }
         }
