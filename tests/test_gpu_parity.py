@@ -335,11 +335,13 @@ def test_large_n_against_c_oracle(n, Emax, B):
     assert np.abs(xg - xc).max() < 1e-12 and np.abs(lpg - lpc).max() < 1e-9 * max(1.0, np.abs(lpc).max())
 
 
-@pytest.mark.parametrize("n,Emax,B,ws", [(29, 25, 5, 1.5), (57, 49, 3, 1.2), (20, 25, 4, 2.0), (33, 25, 3, 1.5), (45, 49, 2, 1.2), (25, 25, 3, 1.5)])
+@pytest.mark.parametrize("n,Emax,B,ws", [(29, 25, 5, 1.5), (57, 49, 3, 1.2), (20, 25, 4, 2.0), (33, 25, 3, 1.5), (45, 49, 2, 1.2), (25, 25, 3, 1.5),
+                                         (32, 25, 3, 1.5), (40, 25, 2, 1.3), (36, 25, 2, 2.0), (56, 49, 2, 1.2)])
 def test_large_n_with_row_exchanges_against_c_oracle(n, Emax, B, ws):
-    """The concurrent, flag-decoupled blocked LUs (cg_blocked_lu_dual) with a flow far from the identity (random weights of
-    standard deviation ws: the Jacobian is not diagonally dominant, the threshold test fails and rows are exchanged inside the
-    panels, with the rest of the exchange deferred to the helpers' column tasks); ragged last panels and blocks (N = 40, 66)."""
+    """The concurrent, flag-decoupled LU pair (cg_blocked_lu_dual2: rows never move, GEMM-only helpers) with a flow far from the identity
+    (random weights of standard deviation ws: the Jacobian is not diagonally dominant, the threshold test fails and the pivots leave the
+    diagonal -- at N > 64 also the register slot the panel code reads, so that a lane's two rows trade slots); ragged last panels and
+    blocks (N = 40, 66, 72), one row per lane up to its limit (N = 64), two rows per lane right above it (N = 66 ... 114)."""
     import ctypes as C
     import coulombgas_amd as cg
     from coulombgas_amd.build import build_oracle
