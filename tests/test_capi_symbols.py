@@ -105,4 +105,7 @@ def test_production_kernels_carry_no_register_spill_scratch(tmp_path):
         hits = {k: v for k, v in seen.items() if w in k}
         assert hits, "kernel %s not found in the library" % w
         for k, v in hits.items():
-            assert v <= 64, "%s: %d B of scratch per lane" % (k, v)
+            # the one deliberate exception (round 4): k_param_vjp<..., 512, WPE = 4>, the instantiation whose registers are capped at 128 so
+            # that two workgroups share a CU at N > 64 -- 224 B of spill scratch buy 20 % of the kernel (csrc/cg_k_derivs.inc)
+            bound = 256 if ("k_param_vjp" in k and "ELi512ELi4EE" in k) else 64
+            assert v <= bound, "%s: %d B of scratch per lane" % (k, v)

@@ -11,7 +11,7 @@ from coulombgas_amd.engine import Engine, DeviceArray
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-Emax = {13: 25, 29: 25, 49: 36, 57: 49}[n]
+Emax = {13: 25, 29: 25, 49: 36, 57: 49}.get(n, 25 if n <= 40 else 49)
 L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
 eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta)
 x_d = DeviceArray.from_numpy(eng, x); s_d = DeviceArray.from_numpy(eng, sidx, np.int32)
