@@ -67,7 +67,7 @@ struct CgDerivs {
     struct Layout { Ws w; Adj a; CgFastLds o; int vjp_fast; int vjp_da; int stage; unsigned mn, mN; };
     static constexpr size_t VJP_LDS_MAX_BYTES = (D == 2 ? 53 : 80) * 1024;      // keeps 3 (d=2) / 2 (d=3) workgroups per CU
     static CG_HD size_t inv_scratch_doubles(int n) { const size_t N = (size_t)n * D; return 2 * N * N + 4 * (size_t)n * n + N + 42; }
-    static CG_HD size_t stage_doubles(int n) { const size_t N = (size_t)n * D; return (5 * N + 64 + 1) & ~(size_t)1; }    // LDS scratch of cg_inverse_tile_*
+    static CG_HD size_t stage_doubles(int n, int nthr) { return cg_inv_panel_scratch(n * D, n, nthr); }    // LDS scratch of cg_inverse_panel_* (0: sizes they do not serve)
     static Layout layout(int n, int nthr = 256, size_t lds_max_bytes = VJP_LDS_MAX_BYTES) {
         Layout l; l.w = ws_layout(n); l.a = adj_layout(n); l.o = cg_fast_layout(n, D, HS, HT, false);
         l.mn = cg_div_magic((unsigned)n); l.mN = cg_div_magic((unsigned)(n * D));
@@ -75,7 +75,7 @@ struct CgDerivs {
         l.vjp_fast = 0; l.vjp_da = 0; l.stage = 0;
         if (sizeof(double) * (base + l.o.total + inv - NN) <= lds_max_bytes) { l.vjp_fast = (int)(l.o.total + inv - NN); l.vjp_da = 1; }
         else if (sizeof(double) * (base + inv) <= lds_max_bytes) l.vjp_fast = (int)inv;
-        else if (sizeof(double) * (base + stage_doubles(n)) <= lds_max_bytes) l.stage = (int)stage_doubles(n);   // in-place inverses on an LDS copy
+        else if (sizeof(double) * (base + stage_doubles(n, nthr)) <= lds_max_bytes) l.stage = (int)stage_doubles(n, nthr);   // register-tiled inverses, their panels staged in LDS
         return l;
     }
     static CG_HD size_t vjp_lds_doubles(const Layout& l) { return (size_t)(l.vjp_fast ? l.vjp_fast : l.stage); }
@@ -142,12 +142,13 @@ struct CgDerivs {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
         double* stg = stage ? stage : sc;       // LDS scratch of the tiled inverses: the staging area, or the old inversion scratch
-        if (!inverted && stg && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
-            // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
-            cg_inverse_tile_real<8, 4>(b, da + o.J, N, N, ws + w.Jinv, N, stg);
+        if (stg) stg = (double*)(((size_t)stg + 15) & ~(size_t)15);    // (16-byte LDS accesses; both areas have the double to spare)
+        if (!inverted && stg && cg_inv_panel_scratch(N, n, b.nthr)) {
+            // larger systems: register-tiled, panel-blocked Gauss-Jordan (every thread a tile of the matrix, two barriers per panel)
+            cg_inverse_panel_real(b, da + o.J, N, N, ws + w.Jinv, N, stg);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
             Dinv = ws + w.Dinv;
-            cg_inverse_tile_complex<4, 4>(b, da + o.Dm, n, n, Dinv, n, stg);
+            cg_inverse_panel_complex(b, da + o.Dm, n, n, Dinv, n, stg);
             inverted = true;
         }
 #elif !defined(__HIPCC__)

@@ -56,7 +56,7 @@ struct CgLap {
         int th_lds, th;     // 1: theta is copied to LDS at doubles offset th
         int P_lds, A_lds, B_lds;             // block placement
         unsigned P_off, A_off, B_off;        // block base (doubles) in its pool
-        int stage_lds; unsigned stage;       // N > 32: staging area of the in-place inverses (matrix + pivot row / column + bookkeeping)
+        int stage_lds; unsigned stage;       // N > 32: scratch of the register-tiled inverses (published panels, pivot rows, bookkeeping)
         unsigned mn, mN;    // multiply-shift constants of e / n and e / (n D) (cg_div_magic)
         // P
         int red, x, gz, xbar, Jinv, Ta, Kd, TaKd_in_P;
@@ -156,9 +156,9 @@ struct CgLap {
             if (lds + sz <= lds_budget_doubles) { in_lds = 1; off = (unsigned)lds; lds += sz; }
             else { in_lds = 0; off = (unsigned)ws; ws += sz; }
         };
-        {   // N > 32: LDS scratch of the register-tiled Gauss-Jordan inverses (cg_inverse_tile_*)
+        {   // N > 32: LDS scratch of the register-tiled Gauss-Jordan inverses (cg_inverse_panel_*)
             const bool wave_inv = N <= 32 && n <= 16 && nthr >= 128 && NN + nn2 >= 128;     // (set-up: register Gauss-Jordan, no staging)
-            const size_t st = wave_inv ? 0 : ev(5 * N + 64);             // pivot row / column (double-buffered), candidates, pivots
+            const size_t st = wave_inv ? 0 : ev(cg_inv_panel_scratch(N, n, nthr));   // panels of the register-tiled inverses (0: sizes they do not serve)
             if (st + ev(NP) <= lds_budget_doubles) { l.stage_lds = 1; l.stage = (unsigned)lds; lds += st; }
             else { l.stage_lds = 0; l.stage = (unsigned)ws; ws += st; }
         }
@@ -285,11 +285,11 @@ struct CgLap {
 #endif
         early = early_done; have_C = early_done && early_C;
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (!inverted && l.stage_lds && ((N + 7) / 8) * ((N + 3) / 4) <= b.nthr && N <= 128 && ((n + 3) / 4) * ((n + 3) / 4) <= b.nthr && n <= 64) {
-            // larger systems: register-tiled Gauss-Jordan (every thread a tile of the matrix, two barriers per column)
-            cg_inverse_tile_real<8, 4>(b, da + o.J, N, N, Jinv, N, mem.st);
+        if (!inverted && l.stage_lds && cg_inv_panel_scratch(N, n, b.nthr)) {
+            // larger systems: register-tiled, panel-blocked Gauss-Jordan (every thread a tile of the matrix, two barriers per panel)
+            cg_inverse_panel_real(b, da + o.J, N, N, Jinv, N, mem.st);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);
-            cg_inverse_tile_complex<4, 4>(b, da + o.Dm, n, n, Dinv, n, mem.st);
+            cg_inverse_panel_complex(b, da + o.Dm, n, n, Dinv, n, mem.st);
             inverted = true;
         }
 #elif !defined(__HIPCC__)

@@ -353,128 +353,188 @@ __device__ __forceinline__ unsigned cg_wave_max_u32(unsigned v) {
 #endif
 
 // ------------------------------------------------------------------------------------------------------------
-// Register-tiled Gauss-Jordan inverse (gfx950; the derivative kernels at 32 < N <= 128).  Every thread keeps a TR x TC tile of
-// the matrix in registers for the whole elimination; rows never move (the pivot of column k is the unused row p_k of largest
-// modulus), so a step is: the owners of column k post their best candidate, everybody picks the winner, the owners of row p_k and
-// of column k publish them (double-buffered in LDS), everybody updates its tile -- two barriers and ~2 TR TC operations per thread
-// and step, no matrix traffic at all (the in-place LDS version above moves the whole matrix through LDS every column: 1.1 ms per
-// walker at N = 114).  In-place bookkeeping: slot k of the tile matrix ends as column p_k of the inverse of the row-permuted system:
-//     A^-1[k][p_j] = S[p_k][j]        (scattered straight to the destination).
-// A, Ainv: any memory; sc: LDS, >= 5 N + 64 doubles (what the callers reserve; exact need below).  Needs ceil(N/TR) ceil(N/TC) <= nthr, ceil(N/TR) <= 16.
+// Register-tiled, panel-blocked Gauss-Jordan inverse (gfx950; the derivative kernels at 32 < N <= 128).  Every thread keeps a TR x TC
+// tile of the matrix in registers for the whole elimination; rows never move (the pivot of column k is the unused row p_k with the
+// largest high word), no matrix traffic at all.  The threads that own tile column kp -- LR adjacent lanes of ONE wave (thread = tile
+// column * LR + tile row) -- run the in-place Gauss-Jordan of their N x TC panel among themselves (pivot search: lane-local + a DPP row
+// reduction; pivot row by readlane: no LDS, no barrier), publish the panel G (= -A[:, panel] P^-1 on the other rows, P^-1 on the pivot
+// rows) minus the identity on the pivot rows, and everybody else applies
+//     A[:, c] += (G - I_piv) A[pivot rows, c]                    (rank TC, the pivot rows as they stood before the panel)
+// to its tile: two barriers per TC columns, and the panel of kp + 1 starts as soon as its owners have updated.  In-place bookkeeping:
+// slot k of the tile matrix ends as column p_k of the inverse of the row-permuted system,  A^-1[k][p_j] = S[p_k][j]  (scattered straight
+// to the destination).  A, Ainv: any memory.
+// History (tools/lu_bench/tile_inv_bench.hip, cycles per real + complex pair at n = 57 / 29): column-at-a-time with the candidates read
+// back one by one 1.10 M; the same with 16-byte reads and padded buffers 644 k / 298 k; panels 410 k / 154 k.  What is left is the
+// panel owners' dependent chain (~1.4 k cycles per column, latency not arithmetic) and the LDS -> register bandwidth of the rank-TC
+// update (96 doubles per 256 operations and thread).
+// Shapes (cg_inv_shape_*): N <= 64: <2,4,32> with ceil(N/4) * 32 threads, or <4,4,16> with ceil(N/4) * 16; N <= 128: <4,8,32> with ceil(N/8) * 32.
+// sc: LDS, 16-byte aligned, cg_inv_panel_scratch() doubles.
 // ------------------------------------------------------------------------------------------------------------
+#ifndef CG_INV_T
+#define CG_INV_T(i)
+#define CG_INV_T_DECL
+#endif
+struct CgInvShape { int TR, TC, LR; };
+CG_HD CgInvShape cg_inv_shape_real(int N, int nthr) {
+    if (N <= 64 && ((N + 3) / 4) * 32 <= nthr) return {2, 4, 32};
+    if (N <= 64 && ((N + 3) / 4) * 16 <= nthr) return {4, 4, 16};
+    if (N <= 128 && ((N + 7) / 8) * 32 <= nthr) return {4, 8, 32};
+    return {0, 0, 0};
+}
+CG_HD CgInvShape cg_inv_shape_complex(int n, int nthr) {
+    if (n <= 64 && ((n + 3) / 4) * 32 <= nthr) return {2, 4, 32};
+    if (n <= 64 && ((n + 3) / 4) * 16 <= nthr) return {4, 4, 16};
+    return {0, 0, 0};
+}
+// LDS doubles of the inverses of an N x N real and an n x n complex matrix (one after the other in the same scratch); 0: not served
+CG_HD size_t cg_inv_panel_scratch(int N, int n, int nthr) {
+    const CgInvShape r = cg_inv_shape_real(N, nthr), c = cg_inv_shape_complex(n, nthr);
+    if (!r.TR || !c.TR) return 0;
+    const size_t NRr = (size_t)((N + r.TR - 1) / r.TR) * r.TR, NCr = (size_t)((N + r.TC - 1) / r.TC) * r.TC;
+    const size_t NRc = (size_t)((n + c.TR - 1) / c.TR) * c.TR, NCc = (size_t)((n + c.TC - 1) / c.TC) * c.TC;
+    const size_t sr = 2 * r.TC * NRr + r.TC * NCr + 8 + (size_t)N, scx = 2 * (2 * c.TC * NRc + c.TC * NCc) + 8 + (size_t)n;
+    return ((sr > scx ? sr : scx) + 1) & ~(size_t)1;
+}
 #if defined(__HIP_DEVICE_COMPILE__)
-// Round 4: what a column cost was latency, not arithmetic (6.5 k cycles per column at N = 114, tools/lu_bench/tile_inv_bench.hip): the
-// candidates were read back one by one (a dependent LDS read + compare + branch per tile row) and the pivot row / column went through
-// single, predicated 8-byte accesses.  Now every thread fetches the <= 16 candidates with 16-byte reads in one round trip and picks the
-// winner branch-free, and the pivot row / column buffers are padded to whole tiles so that they are written and read with unpredicated
-// 16-byte accesses.  sc: LDS, >= 4 NP + 32 + N doubles with NP = N rounded up to 8 (complex: 8 NP + 32 + N, NP = N rounded up to 4), 16-byte aligned.
-template <int TR, int TC>
-__device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+template <int LR>
+__device__ __forceinline__ unsigned cg_group_max_u32(unsigned v, int g0) {      // maximum over the LR (16 / 32) lanes from g0 on; all of them active
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));   // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));   // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));   // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));   // row_shr:8
+    unsigned m = (unsigned)__builtin_amdgcn_readlane((int)v, g0 + 15);
+    if (LR == 32) m = max(m, (unsigned)__builtin_amdgcn_readlane((int)v, g0 + 31));
+    return m;
+}
+template <int TR, int TC, int LR>
+__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     typedef int i4_t __attribute__((ext_vector_type(4)));
-    static_assert(TR % 2 == 0 && TC % 2 == 0, "16-byte accesses");
+    static_assert((TR == 2 || TR == 4 || TR == 8) && TC % 2 == 0 && TC <= 8 && (LR == 16 || LR == 32), "tile shape");
+    constexpr int LTR = TR == 2 ? 1 : TR == 4 ? 2 : 3, LLR = LR == 16 ? 4 : 5;
     const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
-    const bool act = b.tid < trn * tcn;
-    const int tr = act ? b.tid / tcn : 0, tc = act ? b.tid - tr * tcn : 0;
+    const int tc = b.tid >> LLR, tr = b.tid & (LR - 1), lane = b.tid & 63;
+    const bool act = tc < tcn && tr < trn;
     const int i0 = tr * TR, j0 = tc * TC;
-    const int NP = (N + 7) & ~7;
-    double* rowb = sc; double* colb = sc + 2 * NP; double* cv = sc + 4 * NP; int* ci = (int*)(cv + 18); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    const int NR = trn * TR, NC = tcn * TC;
+    double* Et = sc; double* R = sc + 2 * TC * NR; int* prb = (int*)(R + TC * NC); int* piv = prb + 16; int* kinv = piv + N;
     double a[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
-        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (act && i0 + ii < N && j0 + jj < N) ? A[(size_t)(i0 + ii) * lda + j0 + jj] : 0.0;
+        for (int jj = 0; jj < TC; ++jj) {          // (clamped, unpredicated loads)
+            const double v = A[(size_t)(i0 + ii < N ? i0 + ii : N - 1) * lda + (j0 + jj < N ? j0 + jj : N - 1)];
+            a[ii][jj] = (act && i0 + ii < N && j0 + jj < N) ? v : 0.0;
+        }
+    CG_INV_T_DECL
     unsigned used = 0;
 #pragma unroll
-    for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;          // rows beyond the matrix never pivot
-    if (b.tid >= trn && b.tid < 16) { cv[b.tid] = -3.0; ci[b.tid] = 0x7fffffff; }   // candidate slots nobody posts to never win
-    // columns in groups of TC so that the pivot column's index inside its owners' tiles is a compile-time constant
-    for (int kc = 0; kc < N; kc += TC) {
-        const bool mycol = act && j0 == kc;
+    for (int ii = 0; ii < TR; ++ii) if (!act || i0 + ii >= N) used |= 1u << ii;  // rows beyond the matrix never pivot
+    for (int kp = 0; kp < tcn; ++kp) {
+        const int kc = kp * TC, kb = N - kc < TC ? N - kc : TC, buf = kp & 1;
+        CG_INV_T(0)
+        if (tc == kp) {
+            // ---- the panel, in place, among its owners
+            const int g0 = (kp << LLR) & 63;
+            int pr[TC];
 #pragma unroll
-        for (int jk = 0; jk < TC; ++jk) {
-            const int k = kc + jk;
-            if (k < N) {                                  // (workgroup-uniform)
-                const int buf = k & 1;
-                if (mycol) {                              // best unused row of column k in this tile
-                    double best = -2.0; int bi = 0x7fffffff;
+            for (int j = 0; j < TC; ++j) {
+                pr[j] = -1;
+                if (j < kb) {
+                    unsigned best = 0; int bi = 0;
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii) {
-                        const double v = fabs(a[ii][jk]);
-                        const bool free_row = !((used >> ii) & 1u);
-                        if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }     // (an all-NaN column still gets a pivot row)
-                        if (free_row && v > best) { best = v; bi = i0 + ii; }
+                        const unsigned k = ((used >> ii) & 1u) ? 0u : ((unsigned)((unsigned long long)__double_as_longlong(a[ii][j]) >> 32) & 0x7fffffffu) + 1u;
+                        if (k > best) { best = k; bi = ii; }
                     }
-                    cv[tr] = best; ci[tr] = bi;
-                }
-                b.sync();
-                int p;
-                {   // the largest candidate, the first one among equals (= the smallest row: tile rows post in order)
-                    d2_t c2[8]; i4_t q4[4];
+                    const unsigned mx = cg_group_max_u32<LR>(best, g0);
+                    const int pl = (int)__builtin_ctzll(__ballot(best == mx));           // (a free row always exists: mx >= 1)
+                    const int ip = __builtin_amdgcn_readlane(bi, pl);
+                    pr[j] = ((pl & (LR - 1)) << LTR) + ip;
+                    double rr[TC];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) c2[t] = ((const d2_t*)cv)[t];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) q4[t] = ((const i4_t*)ci)[t];
-                    double best = c2[0][0]; p = q4[0][0];
-#pragma unroll
-                    for (int t = 1; t < 16; ++t) { const double v = c2[t >> 1][t & 1]; const bool take = v > best; best = take ? v : best; p = take ? q4[t >> 2][t & 3] : p; }
-                }
-                const bool myrow = act && p >= i0 && p < i0 + TR;
-                const int ip = p - i0;
-                // (every thread of the pivot's tile row has the same ip: made a scalar, the row is picked by uniform branches -- a register
-                // array cannot be indexed by a lane value, and the select chains it took were ~120 instructions on the wave everybody waits for)
-                if (myrow) {
-                    const int ips = __builtin_amdgcn_readfirstlane(ip);     // (inside the branch: the first ACTIVE lane is one of the tile row)
-                    double v[TC];
-#pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) v[jj] = 0.0;
+                    for (int jj = 0; jj < TC; ++jj) rr[jj] = 0.0;
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii)
-                        if (ips == ii) {
+                        if (ip == ii) {                                               // (scalar branch)
 #pragma unroll
-                            for (int jj = 0; jj < TC; ++jj) v[jj] = a[ii][jj];
+                            for (int jj = 0; jj < TC; ++jj) rr[jj] = cg_readlane_f64(a[ii][jj], pl);
                         }
-                    if (mycol) {                                             // the owner of the pivot publishes its reciprocal
-                        const double pvv = v[jk], r0 = __builtin_amdgcn_rcp(pvv);
-                        double r1 = fma(r0, fma(-pvv, r0, 1.0), r0);
-                        r1 = fma(r1, fma(-pvv, r1, 1.0), r1);
-                        cv[16 + buf] = fabs(pvv) > 0.0 ? r1 : r0;
+                    const double pv = rr[j], r0 = __builtin_amdgcn_rcp(pv);
+                    double r1 = fma(r0, fma(-pv, r0, 1.0), r0);
+                    r1 = fma(r1, fma(-pv, r1, 1.0), r1);
+                    const double rinv = fabs(pv) > 0.0 ? r1 : r0;
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const double fr = a[ii][j] * rinv;
+#pragma unroll
+                        for (int jj = 0; jj < TC; ++jj) if (jj != j) a[ii][jj] = fma(-fr, rr[jj], a[ii][jj]);
+                        a[ii][j] = -fr;
                     }
-#pragma unroll
-                    for (int jj = 0; jj < TC; jj += 2) *(d2_t*)(rowb + buf * NP + j0 + jj) = d2_t{v[jj], v[jj + 1]};     // (padding included)
-                    used |= 1u << ip;
-                }
-                if (mycol) {
-#pragma unroll
-                    for (int ii = 0; ii < TR; ii += 2) *(d2_t*)(colb + buf * NP + i0 + ii) = d2_t{a[ii][jk], a[ii + 1][jk]};
-                }
-                if (b.tid == 0) piv[k] = p;
-                b.sync();
-                const double rinv = cv[16 + buf];
-                double rj[TC], cI[TR];
-#pragma unroll
-                for (int jj = 0; jj < TC; jj += 2) { const d2_t t = *(const d2_t*)(rowb + buf * NP + j0 + jj); rj[jj] = t[0] * rinv; rj[jj + 1] = t[1] * rinv; }
-#pragma unroll
-                for (int ii = 0; ii < TR; ii += 2) { const d2_t t = *(const d2_t*)(colb + buf * NP + i0 + ii); cI[ii] = t[0]; cI[ii + 1] = t[1]; }
-#pragma unroll
-                for (int ii = 0; ii < TR; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) a[ii][jj] = fma(-cI[ii], rj[jj], a[ii][jj]);       // every element; row p and column k fixed below
-                if (mycol) {
-#pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) a[ii][jk] = -cI[ii] * rinv;
-                }
-                if (myrow) {
-                    const int ips = __builtin_amdgcn_readfirstlane(ip);
+                    const bool me = lane == pl;
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii)
-                        if (ips == ii) {
+                        if (ip == ii) {
 #pragma unroll
-                            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = (mycol && jj == jk) ? rinv : rj[jj];
+                            for (int jj = 0; jj < TC; ++jj) a[ii][jj] = me ? (jj == j ? rinv : rr[jj] * rinv) : a[ii][jj];
+                        }
+                    if (me) used |= 1u << ip;
+                }
+            }
+            if (tr < trn) {
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < TR; ii += 2)
+                        *(d2_t*)(Et + (buf * TC + j) * NR + i0 + ii) = d2_t{a[ii][j] - (i0 + ii == pr[j] ? 1.0 : 0.0), a[ii + 1][j] - (i0 + ii + 1 == pr[j] ? 1.0 : 0.0)};
+            }
+            if (tr == 0) {
+#pragma unroll
+                for (int j = 0; j < TC; ++j) { prb[buf * 8 + j] = pr[j]; if (j < kb) piv[kc + j] = pr[j]; }
+            }
+        }
+        CG_INV_T(1)
+        b.sync();
+        CG_INV_T(2)
+        const bool upd = act && tc != kp;
+        if (upd) {                                    // the pivot rows as they stand, from the tiles that hold them
+            int pq[8];
+            { const i4_t q0 = *(const i4_t*)(prb + buf * 8), q1 = *(const i4_t*)(prb + buf * 8 + 4);
+              pq[0] = q0[0]; pq[1] = q0[1]; pq[2] = q0[2]; pq[3] = q0[3]; pq[4] = q1[0]; pq[5] = q1[1]; pq[6] = q1[2]; pq[7] = q1[3]; }
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                const int p = __builtin_amdgcn_readfirstlane(pq[j]);
+                if (j < kb && tr == (p >> LTR)) {
+                    const int ip = p & (TR - 1);
+                    used |= 1u << ip;                 // (every tile of the row learns that it has served)
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ip == ii) {
+#pragma unroll
+                            for (int jj = 0; jj < TC; jj += 2) *(d2_t*)(R + j * NC + j0 + jj) = d2_t{a[ii][jj], a[ii][jj + 1]};
                         }
                 }
             }
         }
+        CG_INV_T(3)
+        b.sync();
+        CG_INV_T(4)
+        if (upd) {
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if (j < kb) {
+                    double e[TR], r[TC];
+#pragma unroll
+                    for (int ii = 0; ii < TR; ii += 2) { const d2_t t = *(const d2_t*)(Et + (buf * TC + j) * NR + i0 + ii); e[ii] = t[0]; e[ii + 1] = t[1]; }
+#pragma unroll
+                    for (int jj = 0; jj < TC; jj += 2) { const d2_t t = *(const d2_t*)(R + j * NC + j0 + jj); r[jj] = t[0]; r[jj + 1] = t[1]; }
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < TC; ++jj) a[ii][jj] = fma(e[ii], r[jj], a[ii][jj]);
+                }
+        }
+        CG_INV_T(5)
     }
     b.sync();
     for (int t = b.tid; t < N; t += b.nthr) kinv[piv[t]] = t;
@@ -489,115 +549,136 @@ __device__ __forceinline__ void cg_inverse_tile_real(const CgBlk& b, const doubl
     b.sync();
 }
 // complex version: interleaved (re, im), lda / ldi in complex elements
-template <int TR, int TC>
-__device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+template <int TR, int TC, int LR>
+__device__ __forceinline__ void cg_inverse_panel_complex(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     typedef int i4_t __attribute__((ext_vector_type(4)));
+    static_assert((TR == 2 || TR == 4) && TC <= 8 && (LR == 16 || LR == 32), "tile shape");
+    constexpr int LTR = TR == 2 ? 1 : 2, LLR = LR == 16 ? 4 : 5;
     const int tcn = (N + TC - 1) / TC, trn = (N + TR - 1) / TR;
-    const bool act = b.tid < trn * tcn;
-    const int tr = act ? b.tid / tcn : 0, tc = act ? b.tid - tr * tcn : 0;
+    const int tc = b.tid >> LLR, tr = b.tid & (LR - 1), lane = b.tid & 63;
+    const bool act = tc < tcn && tr < trn;
     const int i0 = tr * TR, j0 = tc * TC;
-    const int NP = (N + 3) & ~3;
-    double* rowb = sc; double* colb = sc + 4 * NP; double* cv = sc + 8 * NP; int* ci = (int*)(cv + 20); int* piv = (int*)(cv + 32); int* kinv = piv + N;
+    const int NR = trn * TR, NC = tcn * TC;
+    double* Et = sc; double* R = sc + 4 * TC * NR; int* prb = (int*)(R + 2 * TC * NC); int* piv = prb + 16; int* kinv = piv + N;
     double ar[TR][TC], ai[TR][TC];
 #pragma unroll
     for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
         for (int jj = 0; jj < TC; ++jj) {
             const bool ok = act && i0 + ii < N && j0 + jj < N;
-            ar[ii][jj] = ok ? A[2 * ((size_t)(i0 + ii) * lda + j0 + jj)] : 0.0;
-            ai[ii][jj] = ok ? A[2 * ((size_t)(i0 + ii) * lda + j0 + jj) + 1] : 0.0;
+            const double* q = A + 2 * ((size_t)(i0 + ii < N ? i0 + ii : N - 1) * lda + (j0 + jj < N ? j0 + jj : N - 1));     // (clamped, unpredicated loads)
+            const double vr = q[0], vi = q[1];
+            ar[ii][jj] = ok ? vr : 0.0; ai[ii][jj] = ok ? vi : 0.0;
         }
     unsigned used = 0;
 #pragma unroll
-    for (int ii = 0; ii < TR; ++ii) if (i0 + ii >= N) used |= 1u << ii;
-    if (b.tid >= trn && b.tid < 16) { cv[b.tid] = -3.0; ci[b.tid] = 0x7fffffff; }
-    for (int kc = 0; kc < N; kc += TC) {
-        const bool mycol = act && j0 == kc;
+    for (int ii = 0; ii < TR; ++ii) if (!act || i0 + ii >= N) used |= 1u << ii;
+    for (int kp = 0; kp < tcn; ++kp) {
+        const int kc = kp * TC, kb = N - kc < TC ? N - kc : TC, buf = kp & 1;
+        if (tc == kp) {
+            const int g0 = (kp << LLR) & 63;
+            int pr[TC];
 #pragma unroll
-        for (int jk = 0; jk < TC; ++jk) {
-            const int k = kc + jk;
-            if (k < N) {
-                const int buf = k & 1;
-                if (mycol) {
-                    double best = -2.0; int bi = 0x7fffffff;
+            for (int j = 0; j < TC; ++j) {
+                pr[j] = -1;
+                if (j < kb) {
+                    unsigned best = 0; int bi = 0;
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii) {
-                        const double v = ar[ii][jk] * ar[ii][jk] + ai[ii][jk] * ai[ii][jk];
-                        const bool free_row = !((used >> ii) & 1u);
-                        if (free_row && bi == 0x7fffffff) { bi = i0 + ii; best = -1.0; }
-                        if (free_row && v > best) { best = v; bi = i0 + ii; }
+                        const double m2 = ar[ii][j] * ar[ii][j] + ai[ii][j] * ai[ii][j];
+                        const unsigned k = ((used >> ii) & 1u) ? 0u : ((unsigned)((unsigned long long)__double_as_longlong(m2) >> 32) & 0x7fffffffu) + 1u;
+                        if (k > best) { best = k; bi = ii; }
                     }
-                    cv[tr] = best; ci[tr] = bi;
-                }
-                b.sync();
-                int p;
-                {
-                    d2_t c2[8]; i4_t q4[4];
+                    const unsigned mx = cg_group_max_u32<LR>(best, g0);
+                    const int pl = (int)__builtin_ctzll(__ballot(best == mx));
+                    const int ip = __builtin_amdgcn_readlane(bi, pl);
+                    pr[j] = ((pl & (LR - 1)) << LTR) + ip;
+                    CgCplx rr[TC];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) c2[t] = ((const d2_t*)cv)[t];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) q4[t] = ((const i4_t*)ci)[t];
-                    double best = c2[0][0]; p = q4[0][0];
-#pragma unroll
-                    for (int t = 1; t < 16; ++t) { const double v = c2[t >> 1][t & 1]; const bool take = v > best; best = take ? v : best; p = take ? q4[t >> 2][t & 3] : p; }
-                }
-                const bool myrow = act && p >= i0 && p < i0 + TR;
-                const int ip = p - i0;
-                if (myrow) {
-                    const int ips = __builtin_amdgcn_readfirstlane(ip);     // (see the real version)
-                    double vr[TC], vi[TC];
-#pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) { vr[jj] = 0.0; vi[jj] = 0.0; }
+                    for (int jj = 0; jj < TC; ++jj) rr[jj] = CgCplx{0.0, 0.0};
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii)
-                        if (ips == ii) {
+                        if (ip == ii) {
 #pragma unroll
-                            for (int jj = 0; jj < TC; ++jj) { vr[jj] = ar[ii][jj]; vi[jj] = ai[ii][jj]; }
+                            for (int jj = 0; jj < TC; ++jj) rr[jj] = CgCplx{cg_readlane_f64(ar[ii][jj], pl), cg_readlane_f64(ai[ii][jj], pl)};
                         }
+                    const CgCplx rinv = cinv(rr[j]);
 #pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) *(d2_t*)(rowb + 2 * (buf * NP + j0 + jj)) = d2_t{vr[jj], vi[jj]};           // (padding included)
-                    if (mycol) { const CgCplx r = cinv({vr[jk], vi[jk]}); *(d2_t*)(cv + 16 + 2 * buf) = d2_t{r.re, r.im}; }
-                    used |= 1u << ip;
-                }
-                if (mycol) {
+                    for (int ii = 0; ii < TR; ++ii) {
+                        const CgCplx fr = cmul({ar[ii][j], ai[ii][j]}, rinv);
 #pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) *(d2_t*)(colb + 2 * (buf * NP + i0 + ii)) = d2_t{ar[ii][jk], ai[ii][jk]};
-                }
-                if (b.tid == 0) piv[k] = p;
-                b.sync();
-                const d2_t rv = *(const d2_t*)(cv + 16 + 2 * buf);
-                const CgCplx rinv = {rv[0], rv[1]};
-                CgCplx rj[TC], cI[TR];
-#pragma unroll
-                for (int jj = 0; jj < TC; ++jj) { const d2_t t = *(const d2_t*)(rowb + 2 * (buf * NP + j0 + jj)); rj[jj] = cmul({t[0], t[1]}, rinv); }
-#pragma unroll
-                for (int ii = 0; ii < TR; ++ii) { const d2_t t = *(const d2_t*)(colb + 2 * (buf * NP + i0 + ii)); cI[ii] = CgCplx{t[0], t[1]}; }
-#pragma unroll
-                for (int ii = 0; ii < TR; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < TC; ++jj) {
-                        const CgCplx t = cmul(cI[ii], rj[jj]);
-                        ar[ii][jj] -= t.re; ai[ii][jj] -= t.im;
+                        for (int jj = 0; jj < TC; ++jj)
+                            if (jj != j) {
+                                ar[ii][jj] = fma(fr.im, rr[jj].im, fma(-fr.re, rr[jj].re, ar[ii][jj]));
+                                ai[ii][jj] = fma(-fr.im, rr[jj].re, fma(-fr.re, rr[jj].im, ai[ii][jj]));
+                            }
+                        ar[ii][j] = -fr.re; ai[ii][j] = -fr.im;
                     }
-                if (mycol) {
-#pragma unroll
-                    for (int ii = 0; ii < TR; ++ii) { const CgCplx ck = cmul(cI[ii], rinv); ar[ii][jk] = -ck.re; ai[ii][jk] = -ck.im; }
-                }
-                if (myrow) {
-                    const int ips = __builtin_amdgcn_readfirstlane(ip);
+                    const bool me = lane == pl;
 #pragma unroll
                     for (int ii = 0; ii < TR; ++ii)
-                        if (ips == ii) {
+                        if (ip == ii) {
 #pragma unroll
                             for (int jj = 0; jj < TC; ++jj) {
-                                const bool pk = mycol && jj == jk;
-                                ar[ii][jj] = pk ? rinv.re : rj[jj].re;
-                                ai[ii][jj] = pk ? rinv.im : rj[jj].im;
+                                const CgCplx t = jj == j ? rinv : cmul(rr[jj], rinv);
+                                ar[ii][jj] = me ? t.re : ar[ii][jj]; ai[ii][jj] = me ? t.im : ai[ii][jj];
                             }
+                        }
+                    if (me) used |= 1u << ip;
+                }
+            }
+            if (tr < trn) {
+#pragma unroll
+                for (int j = 0; j < TC; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii)
+                        *(d2_t*)(Et + 2 * ((buf * TC + j) * NR + i0 + ii)) = d2_t{ar[ii][j] - (i0 + ii == pr[j] ? 1.0 : 0.0), ai[ii][j]};
+            }
+            if (tr == 0) {
+#pragma unroll
+                for (int j = 0; j < TC; ++j) { prb[buf * 8 + j] = pr[j]; if (j < kb) piv[kc + j] = pr[j]; }
+            }
+        }
+        b.sync();
+        const bool upd = act && tc != kp;
+        if (upd) {
+            int pq[8];
+            { const i4_t q0 = *(const i4_t*)(prb + buf * 8), q1 = *(const i4_t*)(prb + buf * 8 + 4);
+              pq[0] = q0[0]; pq[1] = q0[1]; pq[2] = q0[2]; pq[3] = q0[3]; pq[4] = q1[0]; pq[5] = q1[1]; pq[6] = q1[2]; pq[7] = q1[3]; }
+#pragma unroll
+            for (int j = 0; j < TC; ++j) {
+                const int p = __builtin_amdgcn_readfirstlane(pq[j]);
+                if (j < kb && tr == (p >> LTR)) {
+                    const int ip = p & (TR - 1);
+                    used |= 1u << ip;
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii)
+                        if (ip == ii) {
+#pragma unroll
+                            for (int jj = 0; jj < TC; ++jj) *(d2_t*)(R + 2 * (j * NC + j0 + jj)) = d2_t{ar[ii][jj], ai[ii][jj]};
                         }
                 }
             }
+        }
+        b.sync();
+        if (upd) {
+#pragma unroll
+            for (int j = 0; j < TC; ++j)
+                if (j < kb) {
+                    d2_t e[TR], r[TC];
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii) e[ii] = *(const d2_t*)(Et + 2 * ((buf * TC + j) * NR + i0 + ii));
+#pragma unroll
+                    for (int jj = 0; jj < TC; ++jj) r[jj] = *(const d2_t*)(R + 2 * (j * NC + j0 + jj));
+#pragma unroll
+                    for (int ii = 0; ii < TR; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < TC; ++jj) {
+                            ar[ii][jj] = fma(-e[ii][1], r[jj][1], fma(e[ii][0], r[jj][0], ar[ii][jj]));
+                            ai[ii][jj] = fma(e[ii][1], r[jj][0], fma(e[ii][0], r[jj][1], ai[ii][jj]));
+                        }
+                }
         }
     }
     b.sync();
@@ -614,6 +695,18 @@ __device__ __forceinline__ void cg_inverse_tile_complex(const CgBlk& b, const do
                 }
     }
     b.sync();
+}
+// dispatch on the shape (the caller has checked cg_inv_panel_scratch(N, n, nthr) != 0)
+__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+    const CgInvShape s = cg_inv_shape_real(N, b.nthr);
+    if (s.TC == 8) cg_inverse_panel_real<4, 8, 32>(b, A, N, lda, Ainv, ldi, sc);
+    else if (s.LR == 32) cg_inverse_panel_real<2, 4, 32>(b, A, N, lda, Ainv, ldi, sc);
+    else cg_inverse_panel_real<4, 4, 16>(b, A, N, lda, Ainv, ldi, sc);
+}
+__device__ __forceinline__ void cg_inverse_panel_complex(const CgBlk& b, const double* A, int n, int lda, double* Ainv, int ldi, double* sc) {
+    const CgInvShape s = cg_inv_shape_complex(n, b.nthr);
+    if (s.LR == 32) cg_inverse_panel_complex<2, 4, 32>(b, A, n, lda, Ainv, ldi, sc);
+    else cg_inverse_panel_complex<4, 4, 16>(b, A, n, lda, Ainv, ldi, sc);
 }
 #endif
 
