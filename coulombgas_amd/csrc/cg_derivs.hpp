@@ -142,8 +142,11 @@ struct CgDerivs {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
         double* stg = stage ? stage : sc;       // LDS scratch of the tiled inverses: the staging area, or the old inversion scratch
-        if (stg) stg = (double*)(((size_t)stg + 15) & ~(size_t)15);    // (16-byte LDS accesses; both areas have the double to spare)
-        if (!inverted && stg && cg_inv_panel_scratch(N, n, b.nthr)) {
+        if (stg) stg = (double*)(((size_t)stg + 15) & ~(size_t)15);    // (16-byte LDS accesses)
+        // the staging area is sized for them by layout(); the old inversion scratch holds them from n = 2 on (checked: n = 1 falls through)
+        const size_t stg_need = cg_inv_panel_scratch(N, n, b.nthr) + 2;
+        const bool stg_fits = stage || (inv_lds && (size_t)(sc - fast) + stg_need <= fast_cap);
+        if (!inverted && stg && stg_need > 2 && stg_fits) {
             // larger systems: register-tiled, panel-blocked Gauss-Jordan (every thread a tile of the matrix, two barriers per panel)
             cg_inverse_panel_real(b, da + o.J, N, N, ws + w.Jinv, N, stg);
             F::slater_matrix(b, da + o.z, kocc, nullptr, n, da + o.Dm);

@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X): libcoulombgas_hip.so through the C-ABI vs the oracle
 (oracle/cg_ref.py, torch.func restatement of the reference) on the same seeded inputs.
 fp64 tolerances are stated per assertion; BASELINE.json asks for 1e-8 relative on energies."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1140,3 +1142,22 @@ def test_freefermion_pretraining_on_device():
     assert v[-5:, 1].mean() > F_exact - 5 * v[-5:, 2].mean()      # ... and respects the variational bound
     print("pre-training on the device: F %.5f -> %.5f (exact %.5f)" % (v[0, 1], v[-5:, 1].mean(), F_exact))
     eng.close()
+
+
+@pytest.mark.timeout(300)
+def test_panel_inverses_with_full_pivoting_activity(tmp_path):
+    """The register-tiled, panel-blocked Gauss-Jordan inverses of the derivative kernels at n > 16 (csrc/cg_linalg.hpp: cg_inverse_panel_real /
+    _complex) on matrices WITHOUT diagonal dominance -- the flow Jacobians of the parity tests are near the identity and keep the natural
+    pivots, so the rows-never-move bookkeeping, the used-row masks and the partial last panels are exercised here: the development harness
+    (tools/lu_bench/tile_inv_bench.hip) is compiled and run at every tile shape; it checks |A^-1 A - I| and |D^-1 D - I| < 1e-9 itself."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tile_inv_bench")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-o", exe, os.path.join(root, "tools", "lu_bench", "tile_inv_bench.hip")])
+    for n, nt in ((29, 512), (29, 256), (33, 512), (49, 512), (57, 512), (64, 512), (17, 256), (32, 512)):
+        r = subprocess.run([exe, str(n), str(nt), "2", "1", "1"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (n, nt, r.stdout[-500:], r.stderr[-500:])
