@@ -9,7 +9,7 @@ from coulombgas_amd.engine import Engine, DeviceArray
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 29
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-Emax = {13: 25, 29: 25, 49: 36, 57: 49}[n]
+Emax = {13: 25, 29: 25, 49: 36, 57: 49}.get(n, 25 if n <= 40 else 36 if n <= 52 else 49)
 L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
 eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta)
 s_d = DeviceArray.from_numpy(eng, sidx, np.int32)
