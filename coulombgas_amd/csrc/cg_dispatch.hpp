@@ -22,7 +22,7 @@
 #if defined(CG_NO_SPECIALS) || defined(CG_ONLY_3_4_4)
 #define CG_MCMC_SPECIALS(X)
 #else
-#define CG_MCMC_SPECIALS(X) X(2, 16, 16, 13, 64) X(2, 16, 16, 29, 256) X(2, 16, 16, 57, 512)
+#define CG_MCMC_SPECIALS(X) X(2, 16, 16, 13, 64) X(2, 16, 16, 29, 256) X(2, 16, 16, 49, 512) X(2, 16, 16, 57, 512)     /* the sizes of the reference's production runs (data/n_29, n_49, n_57) and of its n = 13 benchmark */
 #endif
 
 static inline bool cg_fast_supported(int depth, int dim, int hs, int ht) {

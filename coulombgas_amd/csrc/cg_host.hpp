@@ -167,13 +167,13 @@ static int finish(cg_ctx* c) {
 }
 
 // workgroup size of the sampler kernels (tools/sampler_threads_sweep.py, round 4, walker-steps/s at the production batch sizes): n = 22: 128 threads
-// 8.53 M against 8.37 M with 256, n = 23: 6.19 M against 7.81 M (the concurrent LU pair wants its helper waves); n = 41 ... 56 (no size-
-// specialised kernel): 768 threads +1.7 ... +3.4 % over 512; n = 57 runs the kernel specialised on 512 threads
+// 8.53 M against 8.37 M with 256, n = 23: 6.19 M against 7.81 M (the concurrent LU pair wants its helper waves); n = 41 ... 56: 512 threads on
+// the 512-thread instantiation (256 registers per lane; these sizes used to run the 1024-thread one with 128: n = 45 1.95 -> 2.58 M, n = 53
+// 1.60 -> 2.00 M; 768 threads on the latter: 2.02 / 1.63 M); n = 29, 49, 57 run kernels specialised on the size as well
 static int auto_threads(int n) {
     if (n <= 16) return 64;
     if (n <= 22) return 128;
     if (n <= 40) return 256;
-    if (n <= 56) return 768;
     if (n <= 64) return 512;
     return 1024;
 }

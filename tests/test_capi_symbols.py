@@ -100,7 +100,7 @@ def test_production_kernels_carry_no_register_spill_scratch(tmp_path):
             if m and name:
                 seen[name] = int(m.group(1))
     want = ("k_grad_lap2ILi2ELi16ELi16E", "k_scoresILi2ELi16ELi16E", "k_param_vjpILi2ELi16ELi16E", "k_mcmcILi2ELi16ELi16ELi64ELi13E",
-            "k_mcmcILi2ELi16ELi16ELi256ELi29E", "k_mcmcILi2ELi16ELi16ELi512ELi57E", "k_chol_block", "k_chol_trsm", "k_chol_xinv", "k_chol_update", "k_fisher")
+            "k_mcmcILi2ELi16ELi16ELi256ELi29E", "k_mcmcILi2ELi16ELi16ELi512ELi49E", "k_mcmcILi2ELi16ELi16ELi512ELi57E", "k_chol_block", "k_chol_trsm", "k_chol_xinv", "k_chol_update", "k_fisher")
     for w in want:
         hits = {k: v for k, v in seen.items() if w in k}
         assert hits, "kernel %s not found in the library" % w
