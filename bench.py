@@ -227,15 +227,15 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
 
 
 def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
-    """OUTSIDE the timed region, extra key `shapes`: BASELINE configs 4 and 5 -- the only configurations the reference published runs for
-    (data/n_29_*, n_57_*) -- at their per-GPU batch: one sampling call (k_mcmc, HIP events), the two derivative kernels and whole SR
+    """OUTSIDE the timed region, extra key `shapes`: BASELINE configs 4 and 5 and the third size the reference published runs for
+    (data/n_29_*, n_49_*, n_57_*) at their per-GPU batch: one sampling call (k_mcmc, HIP events), the two derivative kernels and whole SR
     epochs of coulombgas_amd.train, so that the driver-timed record carries them too (profiles/ holds the same numbers per round)."""
     import coulombgas_amd as cg
     from coulombgas_amd.engine import Engine, DeviceArray
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from flop_count import grad_lap_flops, scores_flops
     out = {}
-    for key, n, B, Emax, B_exact in (("n29", 29, 2048, 25, 256), ("n57", 57, 512, 49, 0)):
+    for key, n, B, Emax, B_exact in (("n29", 29, 2048, 25, 256), ("n49", 49, 512, 36, 0), ("n57", 57, 512, 49, 0)):
         t0 = time.perf_counter()
         L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
         eng = Engine(n, 2, 2, 16, 16, L, sp)
@@ -248,10 +248,11 @@ def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
                 eng.mcmc_dev(d_x, d_s, B, mc_steps, stddev, seed=77 + it, walker_offset=0, logp_buf=d_lp)
                 ts.append(eng.timer_stop()); eng.wrap_dev(d_x, B)
             k_ms = sorted(ts[2:])[1]
-            fl = FLOPS_PER_WALKER_STEP[n]
-            r = {"workload": "n=%d dim=2 Emax=%d batch=%d mc_steps=%d (per-GPU shape of BASELINE config %d)" % (n, Emax, B, mc_steps, 4 if n == 29 else 5),
+            fl = FLOPS_PER_WALKER_STEP.get(n)                  # (SURVEY 8(d) counts n = 13 / 29 / 57)
+            where = {29: "per-GPU shape of BASELINE config 4", 57: "per-GPU shape of BASELINE config 5"}.get(n, "per-GPU shape of the reference's data/n_%d_* runs" % n)
+            r = {"workload": "n=%d dim=2 Emax=%d batch=%d mc_steps=%d (%s)" % (n, Emax, B, mc_steps, where),
                  "kernel_ms": k_ms, "walker_steps_per_s": B * mc_steps / (k_ms * 1e-3),
-                 "frac": fl * B * mc_steps / (k_ms * 1e-3) / 1e12 / peak_tflops, "finite": bool(np.isfinite(d_lp.download()).all())}
+                 "frac": fl * B * mc_steps / (k_ms * 1e-3) / 1e12 / peak_tflops if fl else None, "finite": bool(np.isfinite(d_lp.download()).all())}
             eng.device_mode(False)
             x_d = DeviceArray.from_numpy(eng, d_x.download()); s_d = DeviceArray.from_numpy(eng, sidx, np.int32)
             v_d = eng.randn_d("hutch_v", x.shape, 4321)
