@@ -123,6 +123,30 @@ def test_mcmc_philox_statistics():
     assert np.abs(lpf - eng.logp(xf, s["sidx"])).max() < 1e-10
 
 
+@pytest.mark.parametrize("n,threads", [(24, 256), (45, 512), (23, 256), (41, 512)])
+def test_mcmc_at_sizes_without_a_specialised_kernel(n, threads):
+    """The size-generic instantiations of k_mcmc behind the automatic workgroup size (csrc/cg_host.hpp auto_threads: 256 threads from
+    n = 23, the 512-thread instantiation from n = 41 -- round 4): the trajectory with supplied draws against the oracle, and the chain's
+    own log-probability against the separate log Psi kernel."""
+    import coulombgas_amd as cg
+    from oracle import cg_ref as R
+    s = _setup((n, 2, 16, 16, None, 0.2, 0.1), 3, seed=11)
+    eng = s["flow"].engine(n, 2, s["sp"])
+    assert eng.launch_info()["threads"] == threads
+    steps, std = 3, 0.1
+    noise = s["rng"].standard_normal((steps,) + s["x"].shape)
+    unif = s["rng"].uniform(size=(steps, s["x"].shape[0]))
+    logp = cg.make_logp(cg.make_logpsi(s["flow"], s["sp"], s["L"]))
+    x_new, rate = cg.mcmc(logp.bind(s["theta"], s["sidx"]), s["x"], 0, steps, std, noise=noise, unif=unif)
+    r_logp = R.make_logp(R.make_logpsi(s["rflow"], s["sp"], s["L"]))
+    sb = torch.as_tensor(s["sidx"].astype(np.int64))
+    xr, logpr, rate_r = R.mcmc(lambda xx: r_logp(xx, s["rparams"], sb), R.T(s["x"]), R.T(noise), R.T(unif), steps, std)
+    assert rate == pytest.approx(rate_r, abs=1e-15)
+    assert np.abs(x_new - xr.numpy()).max() < 1e-12
+    xf, lpf, _ = eng.mcmc(s["x"], s["sidx"], 10, 0.1, seed=42)
+    assert np.abs(lpf - eng.logp(xf, s["sidx"])).max() < 1e-9 * np.abs(lpf).max()
+
+
 @pytest.mark.parametrize("n,dim", [(13, 2), (29, 2), (19, 3)])
 def test_ewald(n, dim):
     import coulombgas_amd as cg
