@@ -19,8 +19,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOPS_PER_WALKER_STEP = {13: 0.558e6, 29: 2.80e6, 57: 11.4e6}     # SURVEY 8(d) structured count
-BYTES_PER_WALKER_STEP = {13: 484.0, 29: 1060.0, 57: 2068.0}        # SURVEY 8(d), RNG in-kernel
+FLOPS_PER_WALKER_STEP = {13: 0.558e6, 29: 2.80e6, 49: 8.32e6, 57: 11.4e6}     # SURVEY 8(d) structured count (n = 49: the same formulas, tools/flop_count.py)
+BYTES_PER_WALKER_STEP = {13: 484.0, 29: 1060.0, 49: 1780.0, 57: 2068.0}        # SURVEY 8(d) (36 n + 16), RNG in-kernel
 HBM_PEAK_GBS = 8000.0                                               # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 

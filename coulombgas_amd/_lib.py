@@ -87,6 +87,7 @@ PROTOTYPES = {
     "cg_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "cg_comm_destroy": (None, [C.c_void_p]),
     "cg_allreduce_mean": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "cg_allreduce_sum": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
 }
 
 

@@ -28,7 +28,7 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "coulombgas.h")]
 
 
-HIP_UNITS = ("cg_k_sampler_a.hip", "cg_k_sampler_b.hip", "cg_k_derivs_a.hip", "cg_k_derivs_b.hip", "cg_hip.hip", "cg_k_generic.hip")
+HIP_UNITS = ("cg_k_sampler_a.hip", "cg_k_sampler_b.hip", "cg_k_derivs_a.hip", "cg_k_derivs_b.hip", "cg_k_big.hip", "cg_hip.hip", "cg_k_generic.hip")
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
@@ -73,28 +73,41 @@ def build_diag(name, flags):
     return out
 
 
-def build_emul(force=False):
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]
+
+
+def sanitize_requested():
+    """CG_SANITIZE=1: the CPU-side native libraries (host emulation of the device headers, C oracle) are the AddressSanitizer +
+    UndefinedBehaviorSanitizer builds (tools/sanitize_cpu.sh runs the CPU tests against them; GPU sanitizers are not available)."""
+    return os.environ.get("CG_SANITIZE") == "1"
+
+
+def build_emul(force=False, sanitize=None):
+    sanitize = sanitize_requested() if sanitize is None else sanitize
     src = os.path.join(ROOT, "tests", "host_emul", "cg_emul.cpp")
-    out = os.path.join(ROOT, "tests", "host_emul", "libcg_emul.so")
+    out = os.path.join(ROOT, "tests", "host_emul", "libcg_emul_asan.so" if sanitize else "libcg_emul.so")
     if force or _newer(out, hip_sources() + [src]):
-        _run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out, src])
+        _run(["g++"] + (SAN_FLAGS if sanitize else ["-O2"]) + ["-std=c++17", "-shared", "-fPIC", "-o", out, src])
     return out
 
 
-def build_oracle(force=False):
+def build_oracle(force=False, sanitize=None):
+    sanitize = sanitize_requested() if sanitize is None else sanitize
     src = os.path.join(ROOT, "oracle", "cg_oracle.c")
     outdir = os.path.join(ROOT, "oracle", "_build")
-    out = os.path.join(outdir, "libcg_oracle.so")
+    out = os.path.join(outdir, "libcg_oracle_asan.so" if sanitize else "libcg_oracle.so")
     if not os.path.exists(src):
         return None
     os.makedirs(outdir, exist_ok=True)
     if force or _newer(out, [src]):
-        _run(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", "-o", out, src, "-lm"])
+        _run(["gcc"] + (SAN_FLAGS if sanitize else ["-O3"]) + ["-fopenmp", "-shared", "-fPIC", "-o", out, src, "-lm"])
     return out
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--diag":       # python -m coulombgas_amd.build --diag NAME -DFLAG ...
         build_diag(sys.argv[2], sys.argv[3:]); sys.exit(0)
+    if "--sanitize" in sys.argv:                            # the ASan + UBSan builds of the CPU-side libraries (tools/sanitize_cpu.sh)
+        print(build_emul("--force" in sys.argv, True)); print(build_oracle("--force" in sys.argv, True)); sys.exit(0)
     f = "--force" in sys.argv
     build_hip(f); build_emul(f); build_oracle(f)

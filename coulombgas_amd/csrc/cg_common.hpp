@@ -128,7 +128,7 @@ static inline void cg_tab_fill(double* t) {
     }
 }
 #if defined(__HIPCC__)
-extern __shared__ double cg_dyn_lds[];            // every kernel keeps the table in its first CG_TAB_DOUBLES of LDS
+extern __shared__ __attribute__((aligned(16))) double cg_dyn_lds[];   // every kernel keeps the table in its first CG_TAB_DOUBLES of LDS (16-byte aligned: b128 accesses behind it)
 #define CG_TAB (cg_dyn_lds)
 #else
 #if !defined(__HIPCC__)

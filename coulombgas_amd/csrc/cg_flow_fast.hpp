@@ -123,6 +123,8 @@ struct CgFast {
         bool inline_libm;  // true: keep sincos inline (derivative kernels: see CG_OUTLINE in cg_common.hpp)
         bool wt_resident;  // true: the caller staged the two-particle weights into o.wt once (stage_wt) and nothing overwrites that
                            // slot between evaluations (Metropolis chain at small n); false: jacobian_mfma stages them itself
+        double* Jext;      // not null (large-n derivative kernels, cg_big.hpp): J is assembled there (any memory) instead of at lds + o.J,
+                           // which then only serves as the pair-primal scratch
     };
     struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
     struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
@@ -132,7 +134,7 @@ struct CgFast {
     static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; w.wt_resident = false; }
+    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; w.wt_resident = false; w.Jext = nullptr; }
     static __device__ __forceinline__ void load_pair_cols(const double* __restrict__ th_in, WFrag& w) {
         const double* th = th_in;
         asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
@@ -516,9 +518,9 @@ struct CgFast {
         }
     }
     // J[r][c] = sum_g Bm[r][g] G[g][c]  (r = (i,a), c = (k,b)): the rank-16 term B_i G_k of every block at once
-    static __device__ __forceinline__ void jac_bg_mfma(const CgBlk& b, int n, double* lds, const CgFastLds& o) {
+    static __device__ __forceinline__ void jac_bg_mfma(const CgBlk& b, int n, double* lds, const CgFastLds& o, double* Jext = nullptr) {
         const double *Bm = lds + o.Bm, *G = lds + o.G;
-        double* J = lds + o.J;
+        double* J = Jext ? Jext : lds + o.J;
         const int l = b.tid & 63, col = l & 15, kq = l >> 4;
         const int wave = b.tid >> 6, nw = b.nthr >> 6;
         const int N = n * D, tiles = (N + 15) >> 4;
@@ -582,7 +584,7 @@ struct CgFast {
     static __device__ __forceinline__ void jacobian_mfma(const CgBlk& b, const double* __restrict__ th, const WFrag& w, int n,
                                                          double L, double* lds, const CgFastLds& o) {
         const double *sh = lds + o.sh, *ch = lds + o.ch;
-        double *V = lds + o.V, *Up = lds + o.Up, *J = lds + o.J;
+        double *V = lds + o.V, *Up = lds + o.Up, *J = w.Jext ? w.Jext : lds + o.J;
         const int N = n * D;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
         double* wt = lds + o.wt;
@@ -600,7 +602,7 @@ struct CgFast {
         jac_up_mfma(b, w, n, lds, o);
         b.sync();
         CG_STAMP(7)
-        jac_bg_mfma(b, n, lds, o);
+        jac_bg_mfma(b, n, lds, o, w.Jext);
         b.sync();
         CG_STAMP(8)
         jac_factors_mfma<1>(b, w, n, lds, o, wfl);
@@ -654,6 +656,23 @@ struct CgFast {
         }
         b.sync();
         CG_STAMP(10)
+        if (w.Jext) {
+            // J outside LDS: eight lanes share an entry of the diagonal block (partial sums over k = lane, lane + 8, ..., then a
+            // fixed-order DPP reduction inside the group of eight) instead of n dependent loads per thread
+            const int items = n * D * D;
+            for (int e0 = (b.tid >> 6) << 6; e0 < items * 8; e0 += b.nthr) {
+                const int e = (e0 + (b.tid & 63)) >> 3, sub = b.tid & 7;
+                const bool ok = e < items;
+                const int ec = ok ? e : 0, i = ec / (D * D), r = ec - i * (D * D), a = r / D, bb = r - a * D;
+                double v = 0.0;
+                for (int k = sub; k < n; k += 8)
+                    if (k != i) v -= J[(i * D + a) * N + k * D + bb];
+                { const double t = cg_dpp_f64<0x111>(v); v += sub >= 1 ? t : 0.0; }      // row_shr:1 / 2 / 4 restricted to the group of eight
+                { const double t = cg_dpp_f64<0x112>(v); v += sub >= 2 ? t : 0.0; }
+                { const double t = cg_dpp_f64<0x114>(v); v += sub >= 4 ? t : 0.0; }
+                if (ok && sub == 7) J[(i * D + a) * N + i * D + bb] = v + ((a == bb) ? 1.0 : 0.0);
+            }
+        } else
         for (int e = b.tid; e < n * D * D; e += b.nthr) {
             const int i = e / (D * D), r = e - i * (D * D), a = r / D, bb = r - a * D;
             double v = (a == bb) ? 1.0 : 0.0;

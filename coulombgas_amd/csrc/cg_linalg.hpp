@@ -407,7 +407,7 @@ __device__ __forceinline__ unsigned cg_group_max_u32(unsigned v, int g0) {      
     return m;
 }
 template <int TR, int TC, int LR>
-__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc, bool tr_out = false) {
     typedef double d2_t __attribute__((ext_vector_type(2)));
     typedef int i4_t __attribute__((ext_vector_type(4)));
     static_assert((TR == 2 || TR == 4 || TR == 8) && TC % 2 == 0 && TC <= 8 && (LR == 16 || LR == 32), "tile shape");
@@ -544,7 +544,10 @@ __device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const doub
         for (int ii = 0; ii < TR; ++ii)
 #pragma unroll
             for (int jj = 0; jj < TC; ++jj)
-                if (i0 + ii < N && j0 + jj < N) Ainv[(size_t)kinv[i0 + ii] * ldi + piv[j0 + jj]] = a[ii][jj];
+                if (i0 + ii < N && j0 + jj < N) {              // tr_out: the transposed inverse (what the reverse sweeps read row-wise)
+                    if (tr_out) Ainv[(size_t)piv[j0 + jj] * ldi + kinv[i0 + ii]] = a[ii][jj];
+                    else Ainv[(size_t)kinv[i0 + ii] * ldi + piv[j0 + jj]] = a[ii][jj];
+                }
     }
     b.sync();
 }
@@ -697,11 +700,11 @@ __device__ __forceinline__ void cg_inverse_panel_complex(const CgBlk& b, const d
     b.sync();
 }
 // dispatch on the shape (the caller has checked cg_inv_panel_scratch(N, n, nthr) != 0)
-__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc) {
+__device__ __forceinline__ void cg_inverse_panel_real(const CgBlk& b, const double* A, int N, int lda, double* Ainv, int ldi, double* sc, bool tr_out = false) {
     const CgInvShape s = cg_inv_shape_real(N, b.nthr);
-    if (s.TC == 8) cg_inverse_panel_real<4, 8, 32>(b, A, N, lda, Ainv, ldi, sc);
-    else if (s.LR == 32) cg_inverse_panel_real<2, 4, 32>(b, A, N, lda, Ainv, ldi, sc);
-    else cg_inverse_panel_real<4, 4, 16>(b, A, N, lda, Ainv, ldi, sc);
+    if (s.TC == 8) cg_inverse_panel_real<4, 8, 32>(b, A, N, lda, Ainv, ldi, sc, tr_out);
+    else if (s.LR == 32) cg_inverse_panel_real<2, 4, 32>(b, A, N, lda, Ainv, ldi, sc, tr_out);
+    else cg_inverse_panel_real<4, 4, 16>(b, A, N, lda, Ainv, ldi, sc, tr_out);
 }
 __device__ __forceinline__ void cg_inverse_panel_complex(const CgBlk& b, const double* A, int n, int lda, double* Ainv, int ldi, double* sc) {
     const CgInvShape s = cg_inv_shape_complex(n, b.nthr);
@@ -2558,6 +2561,9 @@ __device__ __forceinline__ void cg_blocked_lu_dual2(const CgBlk& b, double* A, i
             int got = 0;
             if (lane == 0) got = atomicCAS(claim + pick, tq, tq + 1) == tq ? 1 : 0;
             if (!__builtin_amdgcn_readfirstlane(got)) continue;          // another helper took it
+            // acquire side of the chains' plain-store publication: the record, E and pivot-row reads of the task must not be hoisted or
+            // merged above the flag loads / the claim by the compiler (the hardware executes a wave's LDS accesses in order)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             CG_STAMP_START(19)
             const int k0 = tq * PW;
             if (pick < 8) {

@@ -240,6 +240,7 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
     update = make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn, log_prob_vjp, comm=cm)
     rows = []
     for i in range(first_epoch, epochs + 1):                                           # :316-372
+        host_solves = _sr.device_solve_fallbacks()
         acc, accept_acc = update.new_acc(), 0.0
         for a in range(acc_steps):
             key, state_indices, x, accept_rate = sample_stateindices_and_x(key, sampler, params_van, logp, x, params_flow,
@@ -251,6 +252,10 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
         rows.append(row)
         if log is not None and cm.rank == 0:
             log(row)
+        host_solves = _sr.device_solve_fallbacks() - host_solves
+        if host_solves and cm.rank == 0:         # (not part of the data.txt row, whose columns are the reference's: main.py:367-372)
+            warnings.warn("train: epoch %d: %d damped solve(s) were not positive definite on the device and went to the host's "
+                          "symmetric-indefinite solver (matrix download + LAPACK; %d so far)" % (i, host_solves, _sr.device_solve_fallbacks()))
         if ckpt_path is not None and i % ckpt_every == 0:                              # :374-381
             xs = allgather(cm, np.asarray(x))                                          # (world, batch, n, dim) like the reference
             ks = allgather(cm, key.generate_state(2, dtype=np.uint32).astype(np.float64)).astype(np.uint32)

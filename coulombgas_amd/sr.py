@@ -43,6 +43,14 @@ def _ravel_batched(score):
 
 
 _warned_indefinite = [False]
+_host_solves = [0]          # damped solves that left the device ("not positive definite" there): see device_solve_fallbacks()
+
+
+def device_solve_fallbacks():
+    """How many damped solves of this process were rerouted from the GPU to the host's symmetric-indefinite solver because the
+    shifted Fisher matrix was not positive definite on the device.  Each one downloads the matrix (279 MB at P = 5907) and costs
+    seconds of LAPACK inside a training epoch; `train` reports the count of an epoch next to its data.txt row."""
+    return _host_solves[0]
 
 
 def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, center=None):
@@ -66,6 +74,7 @@ def _solve_and_clip(fisher, grads_raveled, damping, max_norm, engine=None, cente
         except CoulombGasError as e:
             if e.code != CG_ERR_STATE:
                 raise
+            _host_solves[0] += 1
             if not _warned_indefinite[0]:
                 import warnings
                 warnings.warn("SR: damped Fisher matrix not positive definite on the device (%s); symmetric-indefinite host solve" % e)

@@ -228,6 +228,9 @@ int cg_comm_create(cg_comm** out, cg_ctx* ctx, int rank, int world, const void* 
 void cg_comm_destroy(cg_comm* comm);
 /* in-place mean over ranks of `count` doubles (DEVICE pointer on the ctx's device) */
 int cg_allreduce_mean(cg_comm* comm, double* buf_dev, size_t count);
+/* in-place SUM over ranks (no 1/world): what the gathers of the checkpoint path are built on -- a rank's walkers in its own slot of
+ * a zero-filled buffer come back bit for bit at any world size (main.py:374-381 collects x over the device axis) */
+int cg_allreduce_sum(cg_comm* comm, double* buf_dev, size_t count);
 /* acceptance rate of the most recent cg_mcmc on ctx: accepted moves / denom (= mc_steps x batch), formed on the device and, with a
  * communicator, averaged over its ranks there -- the lax.pmean of src/MCMC.py:39 without staging the operand through the host.
  * comm may be NULL (this rank alone).  rate: HOST pointer.  Synchronises the stream. */

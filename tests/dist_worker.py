@@ -8,8 +8,49 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def ckpt_main(out_dir):
+    """mode "ckpt": train() with a checkpoint at a world size that is not a power of two (main.py:374-381): every rank records the
+    walkers it hands to the gather; the parent compares them with the file bit for bit and resumes from it"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import coulombgas_amd as cg
+    import coulombgas_amd.driver as drv
+    from coulombgas_amd.comm import set_comm
+    from tests.torch_comm import TorchDistComm
+    from tests import emul_engine
+    from tests.common import orbitals
+
+    class MP:
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    emul_engine.install(MP())
+    comm = TorchDistComm()
+    set_comm(comm)
+    seen = []
+    real = drv.allgather
+    drv.allgather = lambda cm, a: (seen.append(np.array(a, copy=True)), real(cm, a))[1]
+    n, dim, L = 4, 2, 2.0
+    sp = orbitals(dim)
+    flow = cg.FermiNet(2, 4, 4, L)
+    p0 = flow.init(3, np.zeros((n, dim)))
+    samp = cg.GroundStateSampler(n, sp.shape[0])
+    kw = dict(rs=2.0, beta=1 / (4 * 0.15), batch=4, sampler=samp, log_prob=samp.log_prob, mc_therm=1, mc_steps=3, seed=1,
+              ckpt_path=os.path.join(out_dir, "ck"), ckpt_every=2, comm=comm)
+    cg.train(flow, p0, sp, n, dim, L, epochs=2, optimizer=cg.adam(1e-2), **kw)
+    np.savez(os.path.join(out_dir, "ckrank%d.npz" % rank), x=seen[0], keys=seen[1])
+    dist.barrier()
+    seen.clear()
+    _, _, rows = cg.train(flow, p0, sp, n, dim, L, epochs=3, optimizer=cg.adam(1e-2), epoch_finished=2, **kw)     # resume: rank r continues with slot r
+    np.savez(os.path.join(out_dir, "ckresume%d.npz" % rank), rows=np.array(rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_dir = sys.argv[1]
+    if len(sys.argv) > 2 and sys.argv[2] == "ckpt":
+        return ckpt_main(out_dir)
     import torch.distributed as dist
     dist.init_process_group("gloo")           # MASTER_ADDR=127.0.0.1 from the launcher
     rank, world = dist.get_rank(), dist.get_world_size()

@@ -90,7 +90,30 @@ def make_n49():
     make("golden_n49_d2.npz", n, 2, 16, 16, L, d["theta"], d["x"][:2], state_indices(rng, 2, n, sp.shape[0]), sp, 10.0, 6, exact=False)
 
 
+def add_exact_to_large():
+    """(--exact-large, round 5) the reference's DEFAULT Laplacian mode (src/logpsi.py:63-106, jacrev + n d jvp's) at the production
+    sizes: adds `grad_exact1`, `lap_exact1` -- walker 0 only, the AD nest is minutes per walker there -- to golden_n57_d2.npz,
+    golden_n49_d2.npz and golden_n29_d2_rs1.npz.  Every other array of the files is kept as it is."""
+    for name in ("golden_n29_d2_rs1.npz", "golden_n49_d2.npz", "golden_n57_d2.npz"):
+        t0 = time.time()
+        path = os.path.join(HERE, name)
+        g = dict(np.load(path))
+        n, dim, hs, ht, L = int(g["n"]), int(g["dim"]), int(g["spsize"]), int(g["tpsize"]), float(g["L"])
+        flow = R.FermiNet(2, hs, ht, L)
+        params = R.flow_unravel(R.T(g["theta"]), 2, hs, ht, dim)
+        logpsi = R.make_logpsi(flow, g["sp_indices"], L)
+        _, fn = R.make_logpsi_grad_laplacian(logpsi)
+        gr, lp = fn(R.T(g["x"][:1]), params, torch.as_tensor(g["state_idx"][:1].astype(np.int64)))
+        g["grad_exact1"] = gr.numpy(); g["lap_exact1"] = lp.numpy()
+        # the exact gradient is the Hutchinson variants' gradient (tests/test_logpsi.py:151)
+        assert np.abs(g["grad_exact1"][0] - g["grad_split"][0]).max() < 1e-9 * max(1.0, np.abs(g["grad_split"][0]).max())
+        np.savez_compressed(path, **g)
+        print(name, "exact mode, walker 0: %.1fs" % (time.time() - t0), "lap", g["lap_exact1"], flush=True)
+
+
 if __name__ == "__main__":
+    if "--exact-large" in sys.argv:
+        add_exact_to_large(); sys.exit(0)
     if "--n49" in sys.argv:
         make_n49(); sys.exit(0)
     if "--large" in sys.argv:

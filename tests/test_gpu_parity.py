@@ -905,13 +905,18 @@ def test_grad_laplacian_n57_all_memory_placements():
 
 
 @pytest.mark.parametrize("name", ["golden_n57_d2.npz", "golden_n49_d2.npz"])
-def test_two_launch_chunks_at_the_production_batch(name):
-    """BASELINE config 5's per-GPU batch (512 walkers) at n = 57 and n = 49: above N = 64 the derivative kernels run in launches of
-    one workgroup per CU (256 walkers: csrc/cg_k_derivs.inc), so walkers 256 ... 511 go through a SECOND launch that reuses the
-    workspace slots of the first.  (i) determinism; (ii) batch independence bit for bit: rows 256 ... of the full call == the
-    call on x[256:] alone; (iii) the oracle's golden walkers placed INSIDE the second chunk (and one in the first) reproduce the
-    golden gradient / Laplacian / theta-VJP; (iv) the per-sample scores of the second chunk == those of the walkers alone."""
+def test_two_launch_chunks_at_the_production_batch(name, monkeypatch):
+    """BASELINE config 5's per-GPU batch (512 walkers) at n = 57 and n = 49 with the derivative kernels forced into launches of ONE
+    workgroup per CU (256 walkers; CG_BIG_ROUNDS / CG_VJP_PER_CU / CG_LAP_PER_CU = 1: csrc/cg_k_big.hip, cg_k_derivs.inc -- the
+    default is up to four rounds of workgroups per launch), so walkers 256 ... 511 go through a SECOND launch that reuses the
+    workspace slots of the first, in the planned kernels (Hutchinson modes, scores) and in the first generation (theta-VJP without
+    resident scores takes the same score kernel).  (i) determinism; (ii) batch independence bit for bit: rows 256 ... of the full
+    call == the call on x[256:] alone; (iii) the oracle's golden walkers placed INSIDE the second chunk (and one in the first)
+    reproduce the golden gradient / Laplacian / theta-VJP; (iv) the per-sample scores of the second chunk == those of the walkers
+    alone."""
     from coulombgas_amd.engine import Engine
+    for k in ("CG_BIG_ROUNDS", "CG_VJP_PER_CU", "CG_LAP_PER_CU"):
+        monkeypatch.setenv(k, "1")
     g = np.load(GOLDEN_DIR + "/" + name)
     n, dim, L = int(g["n"]), int(g["dim"]), float(g["L"])
     M = g["sp_indices"].shape[0]

@@ -23,6 +23,12 @@ def check_against_golden(eng_factory, name, tol=1e-10, exact=True):
     if exact and "grad" in g:
         gr, lp = eng.grad_laplacian(x, s, 0)
         assert rel(gr, g["grad"]) < tol and rel(lp, g["lap_exact"]) < 10 * tol
+    elif exact:
+        # production sizes (n = 49, 57, n = 29 at rs = 1): the exact mode -- the reference's default, src/logpsi.py:63-106 -- on walker 0
+        # (the oracle's AD nest is minutes per walker there; tests/golden/make_golden_vectors.py --exact-large)
+        assert "lap_exact1" in g, "%s carries no exact-mode Laplacian" % name
+        gr, lp = eng.grad_laplacian(x[:1], s[:1], 0)
+        assert rel(gr, g["grad_exact1"]) < tol and rel(lp, g["lap_exact1"]) < 10 * tol
     gr, lp = eng.grad_laplacian(x, s, 1, v)
     assert rel(gr, g["grad_hutch"]) < tol and rel(lp, g["lap_hutch"]) < 10 * tol
     gr, lp = eng.grad_laplacian(x, s, 2, v)

@@ -461,3 +461,29 @@ def test_transformer_flat_parameter_order_and_missing_engine():
         sampler(params, 0, 8)
     with pytest.raises(RuntimeError):
         log_prob(params, np.array([[0, 1, 2, 3]]))
+
+
+def test_sp_orbitals_and_twist_sort_serve_the_pinned_tables():
+    """src/__init__.py:1 exports sp_orbitals / twist_sort and main.py:79-90 calls them: the package serves the pinned tables
+    (coulombgas_amd/data, written from the reference's own function) under those names and refuses every other grid."""
+    import coulombgas_amd as cg
+    for Emax, M in ((25, 81), (36, 113), (49, 149)):
+        sp_indices, Es = cg.sp_orbitals(2, Emax)                       # main.py:79
+        assert sp_indices.shape == (M, 2) and sp_indices.dtype == np.int64 and Es.shape == (M,)
+        assert (np.diff(Es) >= 0).all() and Es[-1] <= Emax and np.array_equal(Es, (sp_indices ** 2).sum(-1))
+        assert len({tuple(r) for r in sp_indices}) == M
+        assert Es[12] == 4 and Es[28] == 9                               # closed shells n = 13, 29 (main.py:80 Ef = Es[n-1])
+        tw, Etw = cg.twist_sort(sp_indices, np.array([0.25, 0.25]))     # main.py:88
+        assert (np.diff(Etw) >= 0).all()
+        assert np.array_equal(tw[::-1], orbitals(2, Emax))              # main.py:90 == the table every engine test uses
+        with pytest.raises(ValueError):
+            cg.twist_sort(sp_indices, np.array([0.0, 0.5]))
+        with pytest.raises(ValueError):
+            cg.twist_sort(sp_indices[::-1], np.array([0.25, 0.25]))
+    idx3, Es3 = cg.sp_orbitals(3)                                        # tests/test_slater.py:17
+    assert idx3.shape == (1935, 3) and (np.diff(Es3) >= 0).all() and Es3[6] == 1 and Es3[7] == 2
+    t3, E3 = cg.twist_sort(idx3, np.array([0.1, 0.2, 0.3]))
+    assert (np.diff(E3) >= 0).all() and t3.shape == idx3.shape
+    for bad in ((2, 30), (3, 25), (1, 25)):
+        with pytest.raises(ValueError):
+            cg.sp_orbitals(*bad)

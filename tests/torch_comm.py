@@ -23,6 +23,15 @@ class TorchDistComm:
         out = (t / self.world).numpy()
         return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
 
+    def psum(self, a):
+        import torch
+        t = torch.from_numpy(np.array(a, dtype=np.float64, ndmin=1, copy=True))
+        if self.device is not None:
+            t = t.to(self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        out = t.cpu().numpy()
+        return out.reshape(np.shape(a)) if np.ndim(a) else float(out[0])
+
     def pmean_d(self, a, count=None, index=0):
         """array handles of the CPU test engine are numpy arrays: all-reduce in place"""
         if not isinstance(a, np.ndarray):
