@@ -22,6 +22,8 @@
 #include "cg_lap.hpp"
 #include <vector>
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 
 // ------------------------------------------------------------------------------------------------------------
@@ -29,10 +31,10 @@
 // < 0: workspace slot of the workgroup at ~off.
 // ------------------------------------------------------------------------------------------------------------
 struct CgPlan {
-    struct Item { int* slot; unsigned size; int p0, p1, prio; bool must_lds; };
+    struct Item { int* slot; unsigned size; int p0, p1, prio; bool must_lds; const char* name; };
     std::vector<Item> items;
-    void add(int& slot, size_t size, int p0, int p1, int prio, bool must_lds = false) {
-        items.push_back({&slot, (unsigned)((size + 1) & ~(size_t)1), p0, p1, prio, must_lds});
+    void add(int& slot, size_t size, int p0, int p1, int prio, bool must_lds = false, const char* name = "") {
+        items.push_back({&slot, (unsigned)((size + 1) & ~(size_t)1), p0, p1, prio, must_lds, name});
     }
     // false: an array that must live in LDS does not fit
     bool solve(size_t lds_cap, unsigned& lds_total, unsigned& ws_total) {
@@ -67,6 +69,7 @@ struct CgPlan {
                 lds_total = std::max(lds_total, pos + it.size);
             } else {
                 if (it.must_lds) ok = false;
+                if (getenv("CG_PLAN_DEBUG")) fprintf(stderr, "  plan: %s item #%d (%u doubles, phases %d-%d, prio %d) -> workspace\n", it.must_lds ? "MUST-LDS" : "", idx, it.size, it.p0, it.p1, it.prio);
                 const unsigned wp = fit(W, it);
                 W.push_back({wp, it.size, it.p0, it.p1}); *it.slot = ~(int)wp;
                 ws_total = std::max(ws_total, wp + it.size);
@@ -112,7 +115,7 @@ struct CgBig {
     };
     struct LayS {
         LayC c;
-        int m0k, s1k, m1k, s2k;            // copies of the primal temporaries the score row needs at the very end
+        int m0k, s1k, m1k, s2k, Uk;        // copies of the primal temporaries the score row needs at the very end; U behind the assembly
         int Upb, Bb, Vb, Gb, sg1b, Ub, Rb, u2b, u2i, u1b, u1i, m1b, m1i, sums /* su2, su2i, gbb, gbbi */;
         int pW0, pWtJ, pWtR, pWtI, pS;     // per-wave partial sums
         unsigned lds_total, ws_total; int ok;
@@ -120,7 +123,7 @@ struct CgBig {
     struct LayG {
         LayC c;
         CgFastLds oj;                      // Jet2 arena of the directional pass (offsets in Jet2 elements from ja)
-        int Ta, red;
+        int Ta, red, Uk;
         int Lm0, gu1, Lm1, Am, Hk, Ls1, Su2, Lgb, Ls2;                     // forward Laplacian
         int Upb, Bb, Vb, Gb, sg1b, Ub, Rb, u2b, u1b, m1b, m0b, sums, pS;   // reverse sweep
         int xrow, colacc;                                                  // pair pass -> xbar
@@ -165,7 +168,7 @@ struct CgBig {
         pl.add(o.m0, (size_t)n * P, PH_PAIRS, PH_DENSE, 100, true); pl.add(o.m1, (size_t)n * HT, PH_PAIRS, PH_DENSE, 100, true);
         pl.add(o.s1, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true); pl.add(o.s2, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true);
         pl.add(o.sg1, (size_t)n * HS, PH_DENSE, PH_ASM, 90, true); pl.add(o.sg2, (size_t)n * HS, PH_DENSE, PH_ASM, 90, true);
-        pl.add(o.U, N * HS, PH_FACT, PH_ASM, 80, true);
+        pl.add(o.U, N * HS, PH_FACT, PH_JAC, 100, true); pl.add(l.Uk, N * HS, PH_JAC, PH_ASM, 50);
         pl.add(o.V, (size_t)n * F::SPV, PH_FACT, PH_PASSA, 90, true); pl.add(o.Bm, (size_t)n * F::SPB, PH_FACT, PH_PASSA, 90, true);
         pl.add(o.G, (size_t)n * F::SPG, PH_FACT, PH_PASSA, 90, true);
         // kept copies (read once, by the score row)
@@ -205,7 +208,7 @@ struct CgBig {
         pl.add(o.m0, (size_t)n * P, PH_PAIRS, PH_DENSE, 100, true); pl.add(o.m1, (size_t)n * HT, PH_PAIRS, PH_DENSE, 100, true);
         pl.add(o.s1, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true); pl.add(o.s2, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true);
         pl.add(o.sg1, (size_t)n * HS, PH_DENSE, PH_PAIR, 90, true); pl.add(o.sg2, (size_t)n * HS, PH_DENSE, PH_CHAIN, 90, true);
-        pl.add(o.U, N * HS, PH_FACT, PH_PASSB, 80, true);
+        pl.add(o.U, N * HS, PH_FACT, PH_JAC, 100, true); pl.add(l.Uk, N * HS, PH_JAC, PH_PASSB, 50);
         pl.add(o.V, (size_t)n * F::SPV, PH_FACT, PH_PAIR, 90, true); pl.add(o.Bm, (size_t)n * F::SPB, PH_FACT, PH_PASSA, 90, true);
         pl.add(o.G, (size_t)n * F::SPG, PH_FACT, PH_PASSA, 90, true);
         pl.add(l.c.zb, 2 * N, PH_INV, PH_JET, 95, true);
@@ -322,13 +325,15 @@ struct CgBig {
         CG_STAMP_END(25)
     }
     static __device__ __forceinline__ void setup2(const CgBlk& b, const double* __restrict__ th, int n, double L, const CgPl& pl, const LayC& c,
-                                                  typename F::WFrag& wf) {
+                                                  typename F::WFrag& wf, double* Uk) {
         const int N = n * D;
         double* lds = pl.lds;
         const CgFastLds& o = c.o;
         const double* kocc = lds + c.kocc;
         CG_STAMP_START(26)
         F::jacobian(b, th, n, L, lds, o, &wf);
+        for (int e = b.tid; e < N * HS; e += b.nthr) Uk[e] = lds[o.U + e];      // U leaves the arena (read again by pass B and the assembly)
+        b.sync();
         CG_STAMP_END(26)
         CG_STAMP_START(27)
         double* J = pl(c.J); double* JT = pl(c.JT); double* Dm = pl(c.Dm); double* Dinv = pl(c.Dinv);
@@ -668,10 +673,10 @@ struct CgBig {
             for (int e = b.tid; e < n * P; e += b.nthr) m0k[e] = lds[o.m0 + e];
             b.sync();
         }
-        setup2(b, th, n, L, pl, c, wf);
+        setup2(b, th, n, L, pl, c, wf, pl(l.Uk));
         CG_STAMP_END(20)
         CG_STAMP_START(10)
-        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *U = lds + o.U, *gbar = lds + o.gbar;
+        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *U = pl(l.Uk), *gbar = lds + o.gbar;
         const double* zr = lds + c.zb; const double* zi = zr + N;
         const double *m0 = pl(l.m0k), *s1 = pl(l.s1k), *m1 = pl(l.m1k), *s2 = pl(l.s2k);
         double *Upb = lds + l.Upb, *Bb = pl(l.Bb), *Vb = pl(l.Vb), *sg1b = pl(l.sg1b), *Ub = pl(l.Ub), *Rb = pl(l.Rb),
@@ -1148,7 +1153,7 @@ struct CgBig {
         double *Upb = lds + l.Upb, *Bb = pl(l.Bb), *Vb = pl(l.Vb), *Gb = lds + l.Gb, *sg1b = pl(l.sg1b), *Ub = pl(l.Ub), *Rb = pl(l.Rb),
                *u2b = pl(l.u2b), *u1b = pl(l.u1b), *m1b = lds + l.m1b, *m0b = lds + l.m0b, *su2 = lds + l.sums, *gbb = su2 + HS,
                *xrow = lds + l.xrow, *colacc = lds + l.colacc;
-        const Rev rv{sh, ch, sg1, sg2, lds + o.U, V, lds + o.Bm, lds + o.G, JT, lds + l.c.rscr, Upb, Bb, Vb, Gb, sg1b, Ub, Rb, lds + l.pS, nullptr, nullptr};
+        const Rev rv{sh, ch, sg1, sg2, pl(l.Uk), V, lds + o.Bm, lds + o.G, JT, lds + l.c.rscr, Upb, Bb, Vb, Gb, sg1b, Ub, Rb, lds + l.pS, nullptr, nullptr};
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
         const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
@@ -1375,7 +1380,7 @@ struct CgBig {
         const bool exact_phi = mode != 1;
         CG_STAMP_START(20)
         setup(b, th, xg, spk, sidx, n, L, pl, c, wf);
-        setup2(b, th, n, L, pl, c, wf);
+        setup2(b, th, n, L, pl, c, wf, pl(l.Uk));
         CG_STAMP_START(18)
         ta_gemm(b, n, pl(c.Dm), pl(c.Dinv), lds + c.kocc, pl(l.Ta));
         b.sync();

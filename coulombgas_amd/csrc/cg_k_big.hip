@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1) k_scores_big(CgDev m, c
 // scores of B walkers by the planned kernel of the larger systems: 1 launched, 0 not served, < 0 error
 int cg_big_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, double* score) {
     constexpr int D = 2, HS = 16, HT = 16;
-    if (c->dim != D || c->hs != HS || c->ht != HT) return 0;
+    if (c->dim != D || c->hs != HS || c->ht != HT || c->n <= 16) return 0;      // (n <= 16: k_scores, everything in LDS)
     {
         int rc;
         const int n = c->n;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1) k_gradlap_big(CgDev m, 
 // grad / Laplacian of B walkers (Hutchinson modes) by the planned kernel of the larger systems: 1 launched, 0 not served, < 0 error
 int cg_big_grad_lap(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap) {
     constexpr int D = 2, HS = 16, HT = 16;
-    if (c->dim != D || c->hs != HS || c->ht != HT || (mode != 1 && mode != 2) || !v) return 0;
+    if (c->dim != D || c->hs != HS || c->ht != HT || (mode != 1 && mode != 2) || !v || c->n <= 16) return 0;   // (n <= 16: k_grad_lap2 in every mode)
     int rc;
     const int n = c->n;
     if (cg_env_int("CG_BIG", 1) == 0 || cg_env_int("CG_BIG_LAP", 1) == 0) return 0;
