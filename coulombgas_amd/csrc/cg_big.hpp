@@ -101,7 +101,11 @@ struct CgBig {
 
     // phases (life times of the plan); scores: ... PASSA PASSB CHAIN PASSC ASM, grad / Laplacian: ... TK SLATER FWD PASSA PASSB CHAIN PAIR JET
     enum { PH_LOAD = 0, PH_PAIRS, PH_DENSE, PH_FACT, PH_JAC, PH_INV, PH_TK, PH_SLATER, PH_FWD, PH_PASSA, PH_PASSB, PH_CHAIN, PH_PASSC, PH_ASM,
-           PH_PAIR = PH_PASSC, PH_JET = PH_ASM, PH_END = PH_ASM };
+           PH_PAIR = PH_PASSC,
+           PH_JA = PH_ASM,      // jet pass: half-angle jets, pair sums
+           PH_JB, PH_JC,        //           dense tangents; factor tangents, G pass
+           PH_JD, PH_JE,        //           pair pass (J', t2); traces
+           PH_JET = PH_JA, PH_END = PH_JE };
     static constexpr int SPGB = HS * D + 2;                      // per-particle stride of Gbar (padded like G: read with the particle on lanes)
 
     // ---- the part of the layout both kernels share: set-up (flow, Jacobian, the two inverses, g)
@@ -127,7 +131,9 @@ struct CgBig {
         int Lm0, gu1, Lm1, Am, Hk, Ls1, Su2, Lgb, Ls2;                     // forward Laplacian
         int Upb, Bb, Vb, Gb, sg1b, Ub, Rb, u2b, u1b, m1b, m0b, sums, pS;   // reverse sweep
         int xrow, colacc;                                                  // pair pass -> xbar
-        int xj, ja, M;                                                     // jet pass
+        int jp;                                                            // jet pass: pool of full jets (sh, ch, sg1 | m0, m1 / G), LDS
+        int s1t, sg2t, s2t, gbt, zt, Ut, Vt, Bmt, Upt;                     //   (d, dd) tangents, two doubles per entry
+        int Jp, M;                                                         //   J' and M = J^-1 J'
         unsigned lds_total, ws_total; int ok;
     };
 
@@ -199,7 +205,7 @@ struct CgBig {
         const size_t N = (size_t)n * D;
         LayG l; memset(&l, 0, sizeof(l));
         CgPlan pl;
-        plan_common(pl, l.c, n, nthr, PH_FWD, PH_JET, PH_PAIR);
+        plan_common(pl, l.c, n, nthr, PH_FWD, PH_DENSE, PH_JD);
         CgFastLds& o = l.c.o;
         const int nw = l.c.nw;
         const bool phi2 = mode == 1;            // the probe pass needs g, T^a, diag K^ab (v^T hess(log phi) v through z', z'')
@@ -207,15 +213,15 @@ struct CgBig {
         pl.add(l.c.J, N * N, PH_JAC, PH_SLATER, 0);
         pl.add(o.m0, (size_t)n * P, PH_PAIRS, PH_DENSE, 100, true); pl.add(o.m1, (size_t)n * HT, PH_PAIRS, PH_DENSE, 100, true);
         pl.add(o.s1, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true); pl.add(o.s2, (size_t)n * HS, PH_DENSE, PH_DENSE, 100, true);
-        pl.add(o.sg1, (size_t)n * HS, PH_DENSE, PH_PAIR, 90, true); pl.add(o.sg2, (size_t)n * HS, PH_DENSE, PH_CHAIN, 90, true);
-        pl.add(o.U, N * HS, PH_FACT, PH_JAC, 100, true); pl.add(l.Uk, N * HS, PH_JAC, PH_PASSB, 50);
-        pl.add(o.V, (size_t)n * F::SPV, PH_FACT, PH_PAIR, 90, true); pl.add(o.Bm, (size_t)n * F::SPB, PH_FACT, PH_PASSA, 90, true);
+        pl.add(o.sg1, (size_t)n * HS, PH_DENSE, PH_JB, 90, true); pl.add(o.sg2, (size_t)n * HS, PH_DENSE, PH_JB, 90, true);
+        pl.add(o.U, N * HS, PH_FACT, PH_JAC, 100, true); pl.add(l.Uk, N * HS, PH_JAC, PH_JC, 50);
+        pl.add(o.V, (size_t)n * F::SPV, PH_FACT, PH_JD, 90, true); pl.add(o.Bm, (size_t)n * F::SPB, PH_FACT, PH_JD, 90, true);
         pl.add(o.G, (size_t)n * F::SPG, PH_FACT, PH_PASSA, 90, true);
-        pl.add(l.c.zb, 2 * N, PH_INV, PH_JET, 95, true);
-        pl.add(l.c.Kd, 2 * (size_t)D * D * n, PH_INV, phi2 ? PH_JET : PH_SLATER, 95, true);
-        pl.add(l.Ta, 2 * (size_t)D * n * n, PH_TK, phi2 ? PH_JET : PH_SLATER, 1);
-        pl.add(l.red, 8 * (size_t)(nw + 1), PH_LOAD, PH_JET, 100, true);
-        pl.add(l.c.JT, N * N, PH_INV, PH_JET, 2);
+        pl.add(l.c.zb, 2 * N, PH_INV, PH_JE, 95, true);
+        pl.add(l.c.Kd, 2 * (size_t)D * D * n, PH_INV, phi2 ? PH_JE : PH_SLATER, 95, true);
+        pl.add(l.Ta, 2 * (size_t)D * n * n, PH_TK, phi2 ? PH_JE : PH_SLATER, 1);
+        pl.add(l.red, 8 * (size_t)(nw + 1), PH_LOAD, PH_JE, 100, true);
+        pl.add(l.c.JT, N * N, PH_INV, PH_JE, 2);
         pl.add(l.c.rscr, (size_t)nw * 4 * RSA, PH_FWD, PH_PASSB, 100, true);
         // forward Laplacian
         pl.add(l.Lm0, (size_t)n * P, PH_FWD, PH_FWD, 70); pl.add(l.gu1, (size_t)n * HS, PH_FWD, PH_FWD, 70); pl.add(l.Lm1, (size_t)n * HT, PH_FWD, PH_FWD, 70);
@@ -233,28 +239,27 @@ struct CgBig {
         pl.add(l.sums, 2 * HS, PH_CHAIN, PH_CHAIN, 99, true);
         pl.add(l.pS, (size_t)nw * D * HS, PH_PASSA, PH_PASSA, 99, true);
         pl.add(l.xrow, N, PH_PAIR, PH_PAIR, 99, true); pl.add(l.colacc, (size_t)nw * 64 * D, PH_PAIR, PH_PAIR, 99, true);
-        // jet pass: the aliased sampler layout in Jet2 elements (as CgLap::layout), one pool
+        // jet pass.  Full jets (value, d, dd) only where the DPP row passes of cg_flow_fast.hpp want them -- half-angle tables, pair sums,
+        // sg1, G: one LDS pool addressed in Jet2 elements --, (d, dd) tangents next to the arrays of the primal arena everywhere else
         {
             CgFastLds& j = l.oj; memset(&j, 0, sizeof(j)); int t = 0;
             auto tk = [&](int cnt) { int r = t; t += (cnt + 1) & ~1; return r; };
-            j.sh = tk(n * D); j.ch = tk(n * D); j.z = tk(n * D); j.sg1 = tk(n * HS); j.sg2 = tk(n * HS);
-            j.perm = tk(2); j.wt = tk((HT * (P + 1) + 2) / 3 + 1);
+            j.sh = tk(n * D); j.ch = tk(n * D); j.sg1 = tk(n * HS);
             const int base = t;
-            j.m0 = tk(n * P); j.s1 = tk(n * HS); j.m1 = tk(n * HT); j.gbar = tk(HS); j.cb = tk(HS); j.s2 = tk(n * HS);
-            const int end_primal = t;
-            t = base;
-            j.V = tk(n * (HT * D + 2)); j.Bm = tk(n * (HS * D + 2)); j.Up = tk(n * D * P); j.G = tk(n * (HS * D + 2));
-            const int end_jac = t;
-            t = end_primal > end_jac ? end_primal : end_jac;
-            j.J = tk(n * D * n * D);
-            j.U = j.J;
-            if (n * D * HS > n * D * n * D) j.U = tk(n * D * HS);
-            j.Dm = j.J; j.lus = base; j.wave_lu = 0;
-            j.total = t;
+            j.m0 = tk(n * P); j.m1 = tk(n * HT);                          // dead once the dense tangents exist ...
+            const int e1 = t;
+            t = base; j.G = tk(n * (HS * D + 2));                         // ... G overlays them
+            j.total = t > e1 ? t : e1;
         }
-        pl.add(l.xj, 3 * N, PH_JET, PH_JET, 90);
-        pl.add(l.ja, 3 * (size_t)l.oj.total, PH_JET, PH_JET, 0);
-        pl.add(l.M, N * N, PH_JET, PH_JET, 0);
+        pl.add(l.jp, 3 * (size_t)l.oj.total, PH_JA, PH_JD, 100, true);
+        pl.add(l.s1t, 2 * (size_t)n * HS, PH_JB, PH_JB, 60); pl.add(l.s2t, 2 * (size_t)n * HS, PH_JB, PH_JB, 60);
+        pl.add(l.sg2t, 2 * (size_t)n * HS, PH_JB, PH_JC, 60); pl.add(l.gbt, 2 * HS, PH_JB, PH_JB, 99, true);
+        pl.add(l.zt, 2 * N, PH_JB, PH_JE, 99, true);
+        pl.add(l.Ut, 2 * N * HS, PH_JC, PH_JC, 50);
+        pl.add(l.Vt, 2 * (size_t)n * F::SPV, PH_JC, PH_JD, 80); pl.add(l.Bmt, 2 * (size_t)n * F::SPB, PH_JC, PH_JD, 70);
+        pl.add(l.Upt, 2 * N * P, PH_JC, PH_JD, 85);
+        pl.add(l.Jp, N * N, PH_JD, PH_JE, 0);
+        pl.add(l.M, N * N, PH_JE, PH_JE, 0);
         const bool fits = pl.solve(lds_cap_doubles, l.lds_total, l.ws_total);
         l.ok = (fits && shapes_ok(n, nthr) && (mode == 1 || mode == 2)) ? 1 : 0;
         return l;
@@ -279,6 +284,13 @@ struct CgBig {
     static __device__ __forceinline__ double wave_sum(double v) {
         const double r = row_sum15(v);
         return (cg_readlane_f64(r, 15) + cg_readlane_f64(r, 31)) + (cg_readlane_f64(r, 47) + cg_readlane_f64(r, 63));
+    }
+
+    // sum over the lanes of a row group of the pair passes: the whole wave (two = false) or its half of 32 lanes (two = true)
+    static __device__ __forceinline__ double group_sum(double v, bool two, int sub) {
+        const double r = row_sum15(v);
+        const double lo = cg_readlane_f64(r, 15) + cg_readlane_f64(r, 31), hi = cg_readlane_f64(r, 47) + cg_readlane_f64(r, 63);
+        return two ? (sub ? hi : lo) : lo + hi;
     }
 
     struct Feat { double c2[D], s2[D], del, td[D]; };
@@ -338,7 +350,9 @@ struct CgBig {
         CG_STAMP_START(27)
         double* J = pl(c.J); double* JT = pl(c.JT); double* Dm = pl(c.Dm); double* Dinv = pl(c.Dinv);
         double* stg = (double*)(((size_t)(lds + c.stage) + 15) & ~(size_t)15);
+        CG_STAMP_START(0)
         cg_inverse_panel_real(b, J, N, N, JT, N, stg, true);               // J^-T
+        CG_STAMP_END(0)
         F::slater_matrix(b, lds + o.z, kocc, nullptr, n, Dm);
         cg_inverse_panel_complex(b, Dm, n, n, Dinv, n, stg);
         CG_STAMP_END(27)
@@ -675,7 +689,7 @@ struct CgBig {
         }
         setup2(b, th, n, L, pl, c, wf, pl(l.Uk));
         CG_STAMP_END(20)
-        CG_STAMP_START(10)
+        CG_STAMP_START(13)
         const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *U = pl(l.Uk), *gbar = lds + o.gbar;
         const double* zr = lds + c.zb; const double* zi = zr + N;
         const double *m0 = pl(l.m0k), *s1 = pl(l.s1k), *m1 = pl(l.m1k), *s2 = pl(l.s2k);
@@ -691,13 +705,16 @@ struct CgBig {
         const int grp = wave * 4 + rg, ngrp = nw * 4;
         pass_a<true>(b, th, n, L, rv);
         b.sync();
-        CG_STAMP(10)
+        CG_STAMP_END(13)
+        CG_STAMP_START(14)
         gb_gemm(b, n, rv);
         b.sync();
-        CG_STAMP(11)
+        CG_STAMP_END(14)
+        CG_STAMP_START(19)
         pass_b<true>(b, th, n, L, rv);
         b.sync();
-        CG_STAMP(12)
+        CG_STAMP_END(19)
+        CG_STAMP_START(21)
         rb_gemm(b, th, n, rv);
         b.sync();
         // ---- (J1) (F8) (F7) u2bar, both parts
@@ -749,7 +766,8 @@ struct CgBig {
             m1b[e] = ar; m1i[e] = ai;
         }
         b.sync();
-        CG_STAMP(13)
+        CG_STAMP_END(21)
+        CG_STAMP_START(22)
         // ---- pass C (F4/F5): primal part of the pair stream, both parts from one sigmoid
         {
             double wc[D], wsn[D];
@@ -797,7 +815,8 @@ struct CgBig {
             }
         }
         b.sync();
-        CG_STAMP(14)
+        CG_STAMP_END(22)
+        CG_STAMP_START(23)
         // ---- the score row, one owner thread per parameter (fixed summation order), real and imaginary part side by side
         for (int e = b.tid; e < NP; e += b.nthr) {
             double ar = 0, ai = 0;
@@ -861,7 +880,7 @@ struct CgBig {
             }
             *(d2_t*)(score + 2 * e) = d2_t{ar, ai};
         }
-        CG_STAMP_END(15)
+        CG_STAMP_END(23)
     }
 
     // ------------------------------------------------------------------------------------------------------
@@ -1220,9 +1239,12 @@ struct CgBig {
             double cacc[D];
 #pragma unroll
             for (int bb = 0; bb < D; ++bb) cacc[bb] = 0.0;
-            const int k = lane; const bool kin = k < n; const int kc = kin ? k : 0;
-            for (int i = wave; i < n; i += nw) {
-                const bool ok = kin && k != i;
+            // n <= 32: two rows per wave (32 lanes each), otherwise the wave is one row
+            const bool two = n <= 32; const int sub = two ? lane >> 5 : 0, rpw = two ? 2 : 1;
+            const int k = two ? lane & 31 : lane; const bool kin = k < n; const int kc = kin ? k : 0;
+            for (int i0 = wave * rpw; i0 < n; i0 += nw * rpw) {
+                const int ir = i0 + sub; const bool rowok = ir < n; const int i = rowok ? ir : n - 1;
+                const bool ok = kin && rowok && k != i;
                 typename F::PF6 pf; F::own_pair(sh, ch, i, ok ? kc : i, ok, pf);
                 double tc[D], ts[D], td[D];
 #pragma unroll
@@ -1298,8 +1320,8 @@ struct CgBig {
                     rr += pf.rdel * (Td[bb] * pl2 * pf.c2[bb] - td[bb] * tdd);
                     rr = ok ? rr : 0.0;
                     cacc[bb] -= rr;
-                    const double tot = wave_sum(rr);
-                    if (lane == 0) xrow[i * D + bb] = tot;
+                    const double tot = group_sum(rr, two, sub);
+                    if (rowok && k == 0) xrow[i * D + bb] = tot;
                 }
             }
 #pragma unroll
@@ -1309,39 +1331,192 @@ struct CgBig {
         for (int e = b.tid; e < N; e += b.nthr) {
             const int p = e / D, bb = e - p * D;
             double acc = xrow[e];
-            for (int w = 0; w < nw; ++w) acc += colacc[(w * 64 + p) * D + bb];
+            for (int w = 0; w < nw; ++w) {
+                acc += colacc[(w * 64 + p) * D + bb];
+                if (n <= 32) acc += colacc[(w * 64 + 32 + p) * D + bb];
+            }
             grad[2 * e] += acc;
         }
         b.sync();
         CG_STAMP_END(17)
     }
 
-    // second-order jet pass along v: this thread's partial sums of t2 = tr(J^-1 J''), t3 = tr((J^-1 J')^2) and (want_phi2)
-    // v^T hess(log phi) v through z', z''  (CgLap::jet_part with J^-T in place of J^-1)
+    // ------------------------------------------------------------------------------------------------------
+    // second-order jet pass along the probe v: this thread's partial sums of t2 = tr(J^-1 J''), t3 = tr((J^-1 J')^2) and (want_phi2)
+    // v^T hess(log phi) v through z', z''.
+    // The first generation pushed Jet2 numbers through the generic flow code out of a 528 KB workspace arena.  Here the VALUES are the
+    // ones the set-up left in the primal arena (no transcendental is evaluated twice: the jets of the one-particle activations need
+    // sigma only), the per-particle quantities carry (d, dd) tangents next to them, the pair passes are the DPP row passes of
+    // cg_flow_fast.hpp on a small LDS pool of full jets, J'' is contracted with J^-T where its blocks are formed
+    //     t2 = sum_(i != k) sum_ab (J^-T[(i,a)][(k,b)] - J^-T[(i,a)][(i,b)]) J''_ik[a][b]      (J''_ii = -sum_k J''_ik)
+    // and only J' (N x N doubles) is written out.
+    // ------------------------------------------------------------------------------------------------------
+    typedef d2_t T2;
+    static __device__ __forceinline__ Jet2 mk(double v, T2 t) { return Jet2(v, t[0], t[1]); }
+    static __device__ __forceinline__ T2 tg(const Jet2& j) { return T2{j.d, j.dd}; }
+    // tangent of f(u) for a one-particle activation whose sigma(u) = g is known: f' = f1, f'' = f2
+    static __device__ __forceinline__ T2 chain(T2 u, double f1, double f2) { return T2{f1 * u[0], fma(f1, u[1], f2 * (u[0] * u[0]))}; }
+
     static __device__ __forceinline__ void jet_part(const CgBlk& b, const double* __restrict__ th, int n, double L, const CgPl& pl, const LayG& l,
                                                     const double* __restrict__ dir, bool want_phi2, double (&red)[4]) {
         double* lds = pl.lds;
         const int N = n * D;
-        const CgFastLds& oj = l.oj;
-        Jet2* xj = (Jet2*)pl(l.xj); Jet2* ja = (Jet2*)pl(l.ja);
-        const double* x = lds + l.c.x; const double* JT = pl(l.c.JT); double* M = pl(l.M);
+        const CgFastLds& o = l.c.o; const CgFastLds& oj = l.oj;
+        const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up;
+        const double* U = pl(l.Uk);
+        const double* JT = pl(l.c.JT); double* Jp = pl(l.Jp); double* M = pl(l.M);
         const double* zb = lds + l.c.zb; const double* Ta = pl(l.Ta); const double* Kd = lds + l.c.Kd;
-        for (int e = b.tid; e < N; e += b.nthr) xj[e] = Jet2(x[e], dir[e], 0.0);
-        b.sync();
+        Jet2* jp = (Jet2*)(lds + l.jp);
+        Jet2 *shj = jp + oj.sh, *chj = jp + oj.ch, *m0j = jp + oj.m0, *m1j = jp + oj.m1, *sg1j = jp + oj.sg1, *Gj = jp + oj.G;
+        T2 *s1t = (T2*)pl(l.s1t), *s2t = (T2*)pl(l.s2t), *sg2t = (T2*)pl(l.sg2t), *gbt = (T2*)(lds + l.gbt), *zt = (T2*)(lds + l.zt),
+           *Ut = (T2*)pl(l.Ut), *Vt = (T2*)pl(l.Vt), *Bmt = (T2*)pl(l.Bmt), *Upt = (T2*)pl(l.Upt);
+        const double rn = 1.0 / (double)n;
+        const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
+        const int lane = b.tid & 63, wave = b.tid >> 6, nw = b.nthr >> 6;
         CG_STAMP_START(29)
-        F::primal(b, th, (const Jet2*)xj, n, L, ja, oj, nullptr, -1);
+        // (JA) half-angle jets: a = pi x / L, a' = pi v / L, a'' = 0
+        for (int e = b.tid; e < N; e += b.nthr) {
+            const double a1 = dir[e] * (CG_PI / L), sv = sh[e], cv = ch[e];
+            shj[e] = Jet2(sv, cv * a1, -sv * (a1 * a1)); chj[e] = Jet2(cv, -sv * a1, -cv * (a1 * a1));
+        }
+        b.sync();
+        F::primal_pairs_jet_dpp(b, th, n, jp, oj);                  // m0, m1 as full jets (one sigmoid per (pair, unit))
+        b.sync();
+        // (JB) one-particle layers: tangents only, sigma from the arena
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            T2 u = {0.0, 0.0};
+#pragma unroll
+            for (int f = 0; f < P; ++f) u += th[F::o_W0 + f * HS + h] * tg(m0j[i * P + f]);
+            const double g = sg1[e], g1 = g * (1.0 - g), g2 = g1 * (1.0 - 2.0 * g);
+            s1t[e] = chain(u, g, g1);
+            sg1j[e] = mk(g, chain(u, g1, g2));
+        }
+        b.sync();
+        for (int h = b.tid; h < HS; h += b.nthr) {
+            T2 a = {0.0, 0.0};
+            for (int i = 0; i < n; ++i) a += s1t[i * HS + h];
+            gbt[h] = a * rn;
+        }
+        b.sync();
+        for (int e = b.tid; e < n * HS; e += b.nthr) {
+            const int i = e / HS, h = e - i * HS;
+            T2 u = {0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < HS; ++g) u += th[F::o_Wa + g * HS + h] * s1t[i * HS + g] + th[F::o_Wb + g * HS + h] * gbt[g];
+#pragma unroll
+            for (int g = 0; g < HT; ++g) u += th[F::o_Wc + g * HS + h] * tg(m1j[i * HT + g]);
+            const double g = sg2[e], g1 = g * (1.0 - g), g2 = g1 * (1.0 - 2.0 * g);
+            s2t[e] = s1t[e] + chain(u, g, g1);
+            sg2t[e] = chain(u, g1, g2);
+        }
+        b.sync();
+        if (want_phi2) {
+            for (int e = b.tid; e < N; e += b.nthr) {               // z' = v + Wf^T s2', z'' = Wf^T s2''
+                const int i = e / D, a = e - i * D;
+                T2 z = {dir[e], 0.0};
+#pragma unroll
+                for (int h = 0; h < HS; ++h) z += th[F::o_fw + h * D + a] * s2t[i * HS + h];
+                zt[e] = z;
+            }
+        }
         CG_STAMP(29)
-        F::jacobian(b, th, n, L, ja, oj);
+        // (JC) tangents of the per-particle left factors (linear in sg2'), of U' (product of U and sg1), and G as full jets
+        for (int e = b.tid; e < N * HS; e += b.nthr) {
+            const int r = e / HS, g = e - r * HS, i = r / D, a = r - i * D;
+            T2 ua = {0.0, 0.0}, ub = {0.0, 0.0}, vc = {0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < HS; ++h) {
+                const T2 rih = th[F::o_fw + h * D + a] * sg2t[i * HS + h];
+                ua += th[F::o_Wa + g * HS + h] * rih; ub += th[F::o_Wb + g * HS + h] * rih; vc += th[F::o_Wc + g * HS + h] * rih;
+            }
+            Ut[e] = ua; Bmt[F::iB(i, a, g)] = ub; Vt[F::iV(i, a, g)] = vc * rn;
+        }
+        F::g_pass_jet_dpp(b, th, n, L, jp, oj);                     // G_k (full jets) over the dead pair sums
+        b.sync();
+        for (int e = b.tid; e < N * P; e += b.nthr) {
+            const int r = e / P, f = e - r * P, i = r / D;
+            T2 acc = {0.0, 0.0};
+#pragma unroll
+            for (int g = 0; g < HS; ++g) acc += th[F::o_W0 + f * HS + g] * tg(mk(U[r * HS + g], Ut[r * HS + g]) * sg1j[i * HS + g]);
+            Upt[e] = acc * rn;
+        }
+        b.sync();
         CG_STAMP(30)
-        const Jet2* zj = ja + oj.z; const Jet2* Jj = ja + oj.J;
-        double p_re = 0, p_im = 0, t2 = 0, t3 = 0;
+        // (JD) pair pass: a wave owns row i, lane = partner k.  J_ik = -U'_i T_ik - V_i diag(sig_t(u_ik)) Wt^T T_ik + B_i G_k as jets
+        double t2 = 0.0;
+        {
+            const bool two = n <= 32; const int sub = two ? lane >> 5 : 0, rpw = two ? 2 : 1;
+            const int k = two ? lane & 31 : lane; const bool kin = k < n; const int kc = kin ? k : 0;
+            for (int i0 = wave * rpw; i0 < n; i0 += nw * rpw) {
+                const int ir = i0 + sub; const bool rowok = ir < n; const int i = rowok ? ir : n - 1;
+                const bool ok = kin && rowok && k != i;
+                typename F::JPF pf; F::template jet_own_pair<true>(shj, chj, i, kc, ok, pf);
+                Jet2 tc[D], ts[D], td[D];
+#pragma unroll
+                for (int bb = 0; bb < D; ++bb) { tc[bb] = -c1 * pf.s2[bb]; ts[bb] = c1 * pf.c2[bb]; td[bb] = c2c * pf.sr[bb]; }
+                Jet2 Jb[D][D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const int r = i * D + a;
+                    const Jet2 upd = mk(Up[r * P + 2 * D], Upt[r * P + 2 * D]);
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb)
+                        Jb[a][bb] = -(mk(Up[r * P + bb], Upt[r * P + bb]) * tc[bb] + mk(Up[r * P + D + bb], Upt[r * P + D + bb]) * ts[bb] + upd * td[bb]);
+                }
+#pragma unroll 2
+                for (int h = 0; h < HT; ++h) {
+                    const double wd = th[F::o_t0w + 2 * D * HT + h];
+                    Jet2 u = th[F::o_t0b + h] + wd * pf.del, q[D];
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const double wc = th[F::o_t0w + a * HT + h], wsn = th[F::o_t0w + (D + a) * HT + h];
+                        u += wc * pf.c2[a] + wsn * pf.s2[a];
+                        q[a] = wc * tc[a] + wsn * ts[a] + wd * td[a];
+                    }
+                    const Jet2 sg = cg_sigmoid(u);
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const Jet2 vs = mk(V[F::iV(i, a, h)], Vt[F::iV(i, a, h)]) * sg;
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) Jb[a][bb] -= vs * q[bb];
+                    }
+                }
+#pragma unroll 4
+                for (int g = 0; g < HS; ++g) {
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        const Jet2 bg = mk(Bm[F::iB(i, a, g)], Bmt[F::iB(i, a, g)]);
+#pragma unroll
+                        for (int bb = 0; bb < D; ++bb) Jb[a][bb] += bg * Gj[F::iG(kc, g, bb)];
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    const double* row = JT + (size_t)(i * D + a) * N;
+                    double* out = Jp + (size_t)(i * D + a) * N;
+#pragma unroll
+                    for (int bb = 0; bb < D; ++bb) {
+                        const double jd = ok ? Jb[a][bb].d : 0.0, jdd = ok ? Jb[a][bb].dd : 0.0;
+                        t2 = fma(ok ? row[kc * D + bb] - row[i * D + bb] : 0.0, jdd, t2);
+                        const double ds = group_sum(jd, two, sub);      // J'_ii = -sum_(k != i) J'_ik
+                        if (kin && rowok) out[k * D + bb] = k == i ? -ds : jd;
+                    }
+                }
+            }
+        }
+        b.sync();
+        CG_STAMP_END(31)
+        CG_STAMP_START(19)
+        // (JE) traces
+        double p_re = 0, p_im = 0, t3 = 0;
         if (want_phi2) {
             for (int e = b.tid; e < N; e += b.nthr) {
-                p_re += zb[e] * zj[e].dd; p_im += zb[N + e] * zj[e].dd;
+                p_re += zb[e] * zt[e][1]; p_im += zb[N + e] * zt[e][1];
                 const int i = e / D, a = e - i * D;
 #pragma unroll
                 for (int bb = 0; bb < D; ++bb) {
-                    const double zz = zj[e].d * zj[i * D + bb].d;
+                    const double zz = zt[e][0] * zt[i * D + bb][0];
                     p_re += zz * Kd[2 * ((a * D + bb) * n + i)]; p_im += zz * Kd[2 * ((a * D + bb) * n + i) + 1];
                 }
             }
@@ -1350,7 +1525,7 @@ struct CgBig {
                 CgCplx yiq = {0, 0}, yqi = {0, 0};
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const double zi = zj[i * D + a].d, zq = zj[q * D + a].d;
+                    const double zi = zt[i * D + a][0], zq = zt[q * D + a][0];
                     yiq.re += zi * Ta[2 * ((size_t)(a * n + i) * n + q)]; yiq.im += zi * Ta[2 * ((size_t)(a * n + i) * n + q) + 1];
                     yqi.re += zq * Ta[2 * ((size_t)(a * n + q) * n + i)]; yqi.im += zq * Ta[2 * ((size_t)(a * n + q) * n + i) + 1];
                 }
@@ -1358,8 +1533,7 @@ struct CgBig {
                 p_re -= pr.re; p_im -= pr.im;
             }
         }
-        for (int e = b.tid; e < N * N; e += b.nthr) t2 = fma(JT[e], Jj[e].dd, t2);           // sum_(ga, al) J^-1[al][ga] J''[ga][al]
-        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return JT[(size_t)k * N + r]; }, [&](int k, int c) { return Jj[(size_t)k * N + c].d; },
+        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return JT[(size_t)k * N + r]; }, [&](int k, int c) { return Jp[(size_t)k * N + c]; },
                    [&](int r, int c, double v) { M[(size_t)r * N + c] = v; });               // M = J^-1 J' (matrix cores)
         b.sync();
         for (int e = b.tid; e < N * N; e += b.nthr) {
@@ -1367,7 +1541,7 @@ struct CgBig {
             t3 += M[(size_t)al * N + ga] * M[(size_t)ga * N + al];
         }
         red[0] = p_re; red[1] = p_im; red[2] = t2; red[3] = t3;
-        CG_STAMP_END(31)
+        CG_STAMP_END(19)
     }
 
     static __device__ __forceinline__ void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,

@@ -10,10 +10,12 @@ from coulombgas_amd.engine import Engine
 from coulombgas_amd import _lib
 GL = {20: "set-up (flow, J, J^-T, D^-1, g, K, T^a)", 21: "Slater part (J^T g, tr J^T H J)", 23: "forward Laplacian", 22: "reverse sweep (xbar)", 24: "jet pass"}
 GLS = {25: "set-up: x, k_occ, primal", 26: "set-up: Jacobian assembly", 27: "set-up: Slater matrix + both inverses", 28: "set-up: g, diag K", 18: "set-up: T^a (MFMA)",
-       15: "reverse: pass A, Gbar, pass B", 16: "reverse: Rbar + dense chain", 17: "reverse: pair pass + xbar", 29: "jet: primal", 30: "jet: Jacobian assembly", 31: "jet: traces"}
-SC = {20: "set-up (flow, J, J^-T, D^-1, g)", 10: "pass A (U'bar, Bbar, Vbar, Wt partials)", 11: "Gbar (MFMA)", 12: "pass B (sg1bar, Ubar, W0 partials)",
-      13: "Rbar + dense chain", 14: "pass C (primal pair stream)", 15: "score row"}
-SCS = {25: "set-up: x, k_occ, primal", 26: "set-up: Jacobian assembly", 27: "set-up: Slater matrix + both inverses", 28: "set-up: g"}
+       0: "set-up:   of which the real inverse (J^-T)",
+       15: "reverse: pass A, Gbar, pass B", 16: "reverse: Rbar + dense chain", 17: "reverse: pair pass + xbar", 29: "jet: half-angle jets, pair sums, dense tangents",
+       30: "jet: factor tangents, G pass", 31: "jet: pair pass (J', t2)", 19: "jet: traces (M = J^-1 J', t3)"}
+SC = {20: "set-up (flow, J, J^-T, D^-1, g)", 13: "pass A (U'bar, Bbar, Vbar, Wt partials)", 14: "Gbar (MFMA)", 19: "pass B (sg1bar, Ubar, W0 partials)",
+      21: "Rbar + dense chain", 22: "pass C (primal pair stream)", 23: "score row"}
+SCS = {25: "set-up: x, k_occ, primal", 26: "set-up: Jacobian assembly", 27: "set-up: Slater matrix + both inverses", 0: "set-up:   of which the real inverse (J^-T)", 28: "set-up: g"}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 57
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 L, sp, theta, sidx, x = synthetic(n, 2, B, {29: 25, 49: 36, 57: 49}.get(n, 25 if n <= 40 else 49), 0)
