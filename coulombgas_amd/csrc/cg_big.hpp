@@ -45,6 +45,11 @@ struct CgPlan {
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
             const Item &x = items[a], &y = items[b];
             if (x.must_lds != y.must_lds) return x.must_lds;
+            if (x.must_lds) {                       // all of these must fit: longest-lived and largest first packs best
+                const int lx = x.p1 - x.p0, ly = y.p1 - y.p0;
+                if (lx != ly) return lx > ly;
+                return x.size > y.size;
+            }
             if (x.prio != y.prio) return x.prio > y.prio;
             return x.size > y.size;
         });
@@ -349,7 +354,8 @@ struct CgBig {
         CG_STAMP_END(26)
         CG_STAMP_START(27)
         double* J = pl(c.J); double* JT = pl(c.JT); double* Dm = pl(c.Dm); double* Dinv = pl(c.Dinv);
-        double* stg = (double*)(((size_t)(lds + c.stage) + 15) & ~(size_t)15);
+        double* stg = lds + c.stage;        // (16-byte aligned: even offset behind the 16-byte aligned LDS base; NO integer round trip -- the
+                                            //  compiler must keep seeing an LDS pointer, or every panel access becomes a flat instruction: measured 2x)
         CG_STAMP_START(0)
         cg_inverse_panel_real(b, J, N, N, JT, N, stg, true);               // J^-T
         CG_STAMP_END(0)

@@ -1,8 +1,22 @@
 // cg_k_big.hip -- derivative kernels of the larger systems (n > 16), second generation (cg_big.hpp): planned LDS / workspace
 // placement, row passes.  Instantiated for the (dim 2, 16, 16) flow of every shipped run; the other configurations keep the first
 // generation (cg_k_derivs_*.hip).
+#if defined(CG_INV_TRACE)      /* diagnostic builds: cycles of thread 0 per phase of the real panel inverse (panel, barrier, pivot rows, barrier, update) */
+#include <hip/hip_runtime.h>
+__device__ unsigned long long cg_inv_ph[8];
+#define CG_INV_T_DECL unsigned long long tprev_ = 0;
+#define CG_INV_T(i) { if (b.tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); if (i > 0) atomicAdd(&cg_inv_ph[i], t_ - tprev_); tprev_ = t_; } }
+#endif
 #include "cg_host.hpp"
 #include "cg_big.hpp"
+#if defined(CG_INV_TRACE)
+extern "C" int cg_debug_inv_trace(cg_ctx* c, unsigned long long* out8, int clear) {
+    CG_HIP(c, hipStreamSynchronize(c->stream));
+    CG_HIP(c, hipMemcpyFromSymbol(out8, HIP_SYMBOL(cg_inv_ph), sizeof(unsigned long long) * 8));
+    if (clear) { unsigned long long z[8] = {0}; CG_HIP(c, hipMemcpyToSymbol(HIP_SYMBOL(cg_inv_ph), z, sizeof(z))); }
+    return CG_OK;
+}
+#endif
 
 // One walker per workgroup; the workspace slot of a workgroup is indexed by blockIdx.x, the batch goes in launches of `gridDim.x` walkers.
 template <int D, int HS, int HT, int NT>
