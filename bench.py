@@ -190,6 +190,9 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
         out["roofline"] = {kk: {"flop_per_walker": fl[kk], "achieved_tflops": fl[kk] * B / (k[kk] * 1e-3) / 1e12,
                                 "frac_of_fp64_peak": fl[kk] * B / (k[kk] * 1e-3) / 1e12 / peak_tflops} for kk in fl}
         out["roofline"]["note"] = "structured flop counts of tools/flop_count.py (FMA = 2 flops, transcendentals not counted), peak = measured fp64 rate %.1f TFLOP/s" % peak_tflops
+        tr = derivative_traffic(n)
+        if tr:
+            out["traffic"] = tr
     except Exception as e:                                   # noqa: BLE001 -- a reporting extra must not lose the metric line
         out["roofline"] = {"error": repr(e)}
     # whole SR epochs through the driver (main.py:316-346 mirror): zero-temperature sampler, hybrid Fisher SR, walkers in HBM
@@ -223,6 +226,24 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
     except Exception as e:                                   # noqa: BLE001 -- a reporting extra must not lose the metric line
         out["hybrid_epoch_ms"] = None; out["hybrid_epoch"] = "failed: %r" % (e,)
     out["seconds"] = time.perf_counter() - t0
+    return out
+
+
+def derivative_traffic(n):
+    """profiles/traffic_derivs.json (tools/make_traffic_derivs.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the
+    committed tree): HBM-side bytes per walker of the two derivative kernels next to the algorithmic bytes of the call."""
+    path = os.path.join(ROOT, "profiles", "traffic_derivs.json")
+    try:
+        tj = json.load(open(path))["sizes"].get("n%d" % n)
+    except (OSError, ValueError, KeyError):
+        return None
+    if not tj:
+        return None
+    out = {}
+    for kind in ("grad_laplacian", "scores"):
+        if kind in tj:
+            out[kind] = {k: tj[kind][k] for k in ("kernel", "traffic_bytes_per_walker", "algorithmic_bytes_per_walker", "traffic_over_algorithmic")}
+    out["source"] = "profiles/traffic_derivs.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch / walkers per launch)"
     return out
 
 
@@ -270,6 +291,9 @@ def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
             r["grad_laplacian_ms"] = gl; r["scores_ms"] = sc
             r["grad_laplacian_frac"] = grad_lap_flops(n, 2, mode=2) * B / (gl * 1e-3) / 1e12 / peak_tflops
             r["scores_frac"] = scores_flops(n, 2) * B / (sc * 1e-3) / 1e12 / peak_tflops
+            tr = derivative_traffic(n)                         # HBM-side bytes per walker from the committed --pmc passes (not measured in this run)
+            if tr:
+                r["traffic"] = tr
             if B_exact:                                        # the reference's default (exact) Laplacian, on a slice of the batch
                 xe = DeviceArray.from_numpy(eng, x_d.numpy()[:B_exact]); se = DeviceArray.from_numpy(eng, sidx[:B_exact], np.int32)
                 ge = med(lambda: eng.grad_laplacian_d(xe, se, 0, None), reps=1)

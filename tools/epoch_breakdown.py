@@ -8,7 +8,7 @@ from coulombgas_amd import sr as SR
 from coulombgas_amd.synthetic import orbitals, box_length
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-L = box_length(n, 2); sp = orbitals(2, {13: 25, 29: 25, 57: 49}.get(n, 25)); rs = 10.0
+L = box_length(n, 2); sp = orbitals(2, {13: 25, 29: 25, 49: 36, 57: 49}.get(n, 25)); rs = 10.0
 flow = cg.FermiNet(2, 16, 16, L); p0 = flow.init(1, np.zeros((n, 2)))
 samp = cg.GroundStateSampler(n, sp.shape[0])
 pv = None

@@ -6,12 +6,12 @@ TAG=${1:-base}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-for cfg in "13 8192" "29 2048" "57 512"; do
+for cfg in "13 8192" "29 2048" "49 512" "57 512"; do
   set -- $cfg
   python3 tools/deriv_timing.py $1 $2 5 >> $OUT/deriv_timing.txt 2>&1
 done
 cat $OUT/deriv_timing.txt
-for cfg in "13 8192" "29 2048" "57 512"; do
+for cfg in "13 8192" "29 2048" "49 512" "57 512"; do
   set -- $cfg
   rocprofv3 --kernel-trace --stats -d $OUT/stats_n$1 -- python3 tools/deriv_timing.py $1 $2 3 > $OUT/stats_n$1.log 2>&1
   python3 tools/profile_summary.py stats $OUT/stats_n$1 > $OUT/kernel_stats_derivs_n$1_B$2.csv
@@ -23,7 +23,7 @@ for cfg in "13 8192" "29 2048" "57 512"; do
   echo "done n=$1" 
 done
 if [ -f coulombgas_amd/lib/diag/libcg_stamps.so ]; then
-  for cfg in "13 8192" "29 2048" "57 512"; do
+  for cfg in "13 8192" "29 2048" "49 512" "57 512"; do
     set -- $cfg
     if [ "$1" = "13" ]; then COULOMBGAS_HIP_LIB=coulombgas_amd/lib/diag/libcg_stamps.so python3 tools/stamps_gradlap.py $1 $2 2 > $OUT/stamps_gradlap_n$1.txt 2>&1 || true
     else COULOMBGAS_HIP_LIB=coulombgas_amd/lib/diag/libcg_stamps.so python3 tools/stamps_big.py $1 $2 > $OUT/stamps_big_n$1.txt 2>&1 || true; fi

@@ -4,11 +4,15 @@
 #   file bench.py reads, the same for the derivative kernels at n = 13 / 29 / 57 (tools/gpu_baseline_derivs.sh), kernel stats of SR and
 #   hybrid epochs, the damped solve at P = 5907 (kernel stats + a stretch of the two-stream timeline), bench lines + sampler stamps at
 #   n = 29 / 57.
+#   tools/gpu_profiles.sh TAG 1 : the first half (bench + its counters, derivative kernels);  TAG 2 : the rest;  no stage: everything
+#   (one gpurun call is limited to 20 minutes)
 set -e
 TAG=${1:-prof}
+STAGE=${2:-0}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "$STAGE" != "2" ]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done: $(cut -c1-160 $OUT/bench.json)"
 rocprofv3 --kernel-trace --stats -d $OUT/st_bench -- python3 bench.py --no-cpu-baseline --no-energy-check --no-update-extras > $OUT/bench_under_rocprof.json 2> $OUT/st_bench.log
@@ -20,12 +24,15 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_
 done
 echo "bench counters done"
 bash tools/gpu_baseline_derivs.sh $TAG/derivs > $OUT/derivs.log 2>&1
+python3 tools/make_traffic_derivs.py $OUT/derivs $OUT/traffic_derivs.json "$TAG" > /dev/null
 echo "derivative kernels done"
+fi
+if [ "$STAGE" = "1" ]; then ls $OUT; exit 0; fi
 rocprofv3 --kernel-trace --stats -d $OUT/st_sr -- python3 tools/epoch_timing.py 13 8192 > $OUT/sr_epoch_rows.txt 2> $OUT/st_sr.log
 python3 tools/profile_summary.py stats $OUT/st_sr > $OUT/kernel_stats_sr_epoch_n13_B8192.csv
 rocprofv3 --kernel-trace --stats -d $OUT/st_hyb -- python3 tools/epoch_breakdown.py 13 8192 --van > $OUT/hybrid_epoch_breakdown.txt 2> $OUT/st_hyb.log
 python3 tools/profile_summary.py stats $OUT/st_hyb > $OUT/kernel_stats_hybrid_epoch_n13_B8192.csv
-for cfg in "13 8192" "29 2048" "57 512"; do set -- $cfg; python3 tools/epoch_breakdown.py $1 $2 > $OUT/epoch_breakdown_n$1.txt 2>&1; done
+for cfg in "13 8192" "29 2048" "49 512" "57 512"; do set -- $cfg; python3 tools/epoch_breakdown.py $1 $2 > $OUT/epoch_breakdown_n$1.txt 2>&1; done
 ( echo "finite-temperature epochs (both parameter sets trained) at the per-GPU shapes of BASELINE configs 4 / 5 (tools/epoch_breakdown.py N B --van)"
   for cfg in "29 2048" "57 512"; do set -- $cfg; echo; echo "== n=$1 B=$2"; python3 tools/epoch_breakdown.py $1 $2 --van 2>&1 | tail -n 8; done ) > $OUT/hybrid_epoch_breakdown_n29_n57.txt
 for cfg in "13 8192" "29 2048" "57 512"; do set -- $cfg; python3 tools/van_timing.py $1 $2 >> $OUT/van_timing.txt 2>&1; done

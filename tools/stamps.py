@@ -18,7 +18,7 @@ NAMES = ["proposal+rng", "sincos", "primal pairs", "primal dense", "wt staging",
 #  16 / 17 and 20-28 are one wave each)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-Emax = {13: 25, 29: 25, 57: 49}[n]
+Emax = {13: 25, 29: 25, 49: 36, 57: 49}[n]
 L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
 eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta); eng.device_mode(True)
 d_x = eng.alloc((B, n, 2)).upload(x); d_s = eng.alloc((B, n), np.int32).upload(sidx); d_lp = eng.alloc((B,))

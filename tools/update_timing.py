@@ -8,7 +8,7 @@ from coulombgas_amd.engine import Engine
 import coulombgas_amd as cg
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-Emax = {13: 25, 29: 25, 57: 49}[n]
+Emax = {13: 25, 29: 25, 49: 36, 57: 49}[n]
 L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 0)
 eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta)
 eng.set_ewald(10, cg.kpoints(2, 15), 10.0)
