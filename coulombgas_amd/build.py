@@ -28,7 +28,7 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "coulombgas.h")]
 
 
-HIP_UNITS = ("cg_k_sampler_a.hip", "cg_k_sampler_b.hip", "cg_k_derivs_a.hip", "cg_k_derivs_b.hip", "cg_k_big.hip", "cg_hip.hip", "cg_k_generic.hip")
+HIP_UNITS = ("cg_k_sampler_a.hip", "cg_k_sampler_b.hip", "cg_k_derivs_a.hip", "cg_k_derivs_b.hip", "cg_k_big.hip", "cg_k_van.hip", "cg_hip.hip", "cg_k_generic.hip")
 HIP_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 

@@ -246,6 +246,8 @@ __global__ void __launch_bounds__(256) k_peak_mfma64(double* out, int iters, dou
     if (s == 12345.678) out[0] = s;
 }
 
+int cg_van_grad_par_launch(cg_ctx* c, const int* sidx_dev, int B, double* S);      // cg_k_van.hip: positions-in-parallel reverse pass of the Transformer
+
 extern "C" {
 
 const char* cg_last_error(const cg_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -624,6 +626,9 @@ int cg_van_scores_compute(cg_ctx* c, const int32_t* state_idx, int B) {
         if (hipMalloc((void**)&c->d_van_scores, need) != hipSuccess) CG_FAIL(c, CG_ERR_HIP, "cg_van_scores_compute: %zu bytes for the classical scores could not be allocated", need);
         c->van_scores_cap = need;
     }
+    // the shipped architecture: positions in parallel (cg_van_par.hpp, cg_k_van.hip); every other model: tokens in sequence, below
+    if ((rc = cg_van_grad_par_launch(c, (const int*)as.dev, B, c->d_van_scores)) < 0) return rc;
+    if (rc == 1) { c->van_scores_B = B; return finish(c); }
     const size_t pbytes = sizeof(double) * (size_t)((m.total + 1) & ~1), wbytes = sizeof(double) * (size_t)cg_van_grad_wave_doubles(m);
     // workgroup shape: as many waves per CU as the 160 KB of LDS allow with the weights staged once per workgroup (the kernel is
     // latency-bound: one wave per SIMD left it at 8.0 ms for B = 8192, n = 13)

@@ -1145,6 +1145,42 @@ def test_transformer_reverse_pass_on_device():
     eng.close()
 
 
+@pytest.mark.parametrize("n,M,B", [(5, 12, 70), (24, 40, 33), (33, 81, 20), (64, 113, 9)])
+def test_transformer_positions_in_parallel_reverse_pass(n, M, B, monkeypatch):
+    """csrc/cg_van_par.hpp (the per-sample gradient of log p with the positions on the lanes of a wave, weight gradients on the matrix
+    cores; shipped architecture, the default from n = 20 on), forced at ragged sizes -- fewer orbitals than one 16-column tile, n = 64
+    (every lane but one a position), orbital counts that are no multiple of 16 -- against the host numpy backward at 1e-12 and
+    against torch autograd through the oracle's restatement (src/sampler.py:40-46, 65)."""
+    import coulombgas_amd as cg
+    from coulombgas_amd.engine import Engine
+    from coulombgas_amd.sr import ravel_pytree, _ravel_batched
+    from oracle import cg_ref as R
+    monkeypatch.setenv("CG_VAN_PAR", "1")
+    rng = np.random.default_rng(100 + n)
+    sp = orbitals(2)[-M:] if M <= 25 else orbitals(2, 25)[:M] if M <= 81 else orbitals(2, 36)[:M]
+    eng = Engine(n, 2, 2, 16, 16, box_length(n, 2), sp)
+    van = cg.Transformer(M, 2, 16, 4, 32)
+    params = van.init(rng, sp[:n])
+    for mod in params:
+        for leaf in params[mod]:
+            params[mod][leaf] = params[mod][leaf] + 0.3 * rng.standard_normal(params[mod][leaf].shape)
+    sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, M, engine=eng)
+    _, hlp = make_host_sampler(van, sp, n, M)
+    s_d = sampler(params, 3, B)
+    s = np.asarray(s_d)
+    S = np.asarray(log_prob.grad(params, s_d))
+    Sh = _ravel_batched(hlp.grad(params, s))
+    scale = np.abs(Sh).max()
+    assert S.shape == Sh.shape and np.abs(S - Sh).max() < 1e-12 * scale, np.abs(S - Sh).max() / scale
+    for b in range(2):
+        tp = {m: {l: R.T(v).clone().requires_grad_(True) for l, v in params[m].items()} for m in params}
+        lp = R.autoregressive_log_prob(tp, torch.as_tensor(s[b].astype(np.int64)), R.T(sp), 2, 4)
+        lp.backward()
+        gref = ravel_pytree({m: {l: tp[m][l].grad.numpy() for l in tp[m]} for m in tp})[0]
+        assert np.abs(S[b] - gref).max() < 1e-12 * scale
+    eng.close()
+
+
 def test_freefermion_pretraining_on_device():
     """f4 (src/freefermion/pretraining.py:34-108) with the density matrix sampled and evaluated on the GPU and the classical
     Fisher matrix formed there: natural-gradient pre-training of a small Transformer lowers F = <log p / beta + E> towards the

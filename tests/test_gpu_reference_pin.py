@@ -176,10 +176,20 @@ def test_transformer_score_kernel_variants_agree_bit_for_bit(n, Emax, fixture, m
     sampler, log_prob = cg.make_autoregressive_sampler(van, sp, n, sp.shape[0], engine=eng)
     s_d = sampler(pv, 3, 96)
     out = {}
+    # the positions-in-parallel kernel of the shipped architecture (csrc/cg_van_par.hpp; the default from n = 20 on) FIRST, into the
+    # fresh score buffer (an entry it failed to write could not hide behind a value another kernel left there): deterministic
+    monkeypatch.setenv("CG_VAN_PAR", "1")
+    par = np.array(log_prob.grad(pv, s_d))
+    s_d.version += 1                                       # (defeat the engine's cache of resident scores)
+    par2 = np.array(log_prob.grad(pv, s_d))
+    assert np.array_equal(par, par2)
+    monkeypatch.setenv("CG_VAN_PAR", "0")                  # the token-sequential kernels (every other architecture runs them)
     for mode in ("-1", "0", "2"):
         monkeypatch.setenv("CG_VAN_GRAD_REG", mode)
-        s_d.version += 1                                   # (defeat the engine's cache of resident scores)
+        s_d.version += 1
         out[mode] = np.array(log_prob.grad(pv, s_d))
     assert np.isfinite(out["-1"]).all() and np.abs(out["-1"]).max() > 0
     assert np.array_equal(out["-1"], out["0"]) and np.array_equal(out["-1"], out["2"])
+    # another order of summation (positions summed on the matrix cores): the same scores to round-off
+    assert np.abs(par - out["-1"]).max() < 1e-12 * np.abs(out["-1"]).max()
     eng.close()

@@ -10,5 +10,5 @@ for u in $units; do
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o coulombgas_amd/lib/libcoulombgas_hip.so build/hip/cg_k_sampler_a.o build/hip/cg_k_sampler_b.o build/hip/cg_k_derivs_a.o build/hip/cg_k_derivs_b.o build/hip/cg_k_big.o build/hip/cg_hip.o build/hip/cg_k_generic.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o coulombgas_amd/lib/libcoulombgas_hip.so build/hip/cg_k_sampler_a.o build/hip/cg_k_sampler_b.o build/hip/cg_k_derivs_a.o build/hip/cg_k_derivs_b.o build/hip/cg_k_big.o build/hip/cg_k_van.o build/hip/cg_hip.o build/hip/cg_k_generic.o -ldl
 echo "relinked"

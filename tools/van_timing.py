@@ -12,7 +12,7 @@ from tests.common import orbitals, box_length, GOLDEN
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 13
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 Emax = {13: 25, 29: 25, 49: 36, 57: 49}[n]
-z = np.load(os.path.join(GOLDEN, {13: "pretrained_van_n13.npz", 29: "shipped_n29_rs10_van.npz", 57: "shipped_n57_rs10_van.npz"}[n]))
+z = np.load(os.path.join(GOLDEN, {13: "pretrained_van_n13.npz", 29: "shipped_n29_rs10_van.npz", 49: "pretrained_van_n49.npz", 57: "shipped_n57_rs10_van.npz"}[n]))
 pv = {}
 for k in z.files:
     if "|" in k:
