@@ -132,7 +132,7 @@ struct CgBig {
     struct LayG {
         LayC c;
         CgFastLds oj;                      // Jet2 arena of the directional pass (offsets in Jet2 elements from ja)
-        int Ta, red, Uk;
+        int Ta, red, Uk, rscrF;
         int Lm0, gu1, Lm1, Am, Hk, Ls1, Su2, Lgb, Ls2;                     // forward Laplacian
         int Upb, Bb, Vb, Gb, sg1b, Ub, Rb, u2b, u1b, m1b, m0b, sums, pS;   // reverse sweep
         int xrow, colacc;                                                  // pair pass -> xbar
@@ -227,10 +227,11 @@ struct CgBig {
         pl.add(l.Ta, 2 * (size_t)D * n * n, PH_TK, phi2 ? PH_JE : PH_SLATER, 1);
         pl.add(l.red, 8 * (size_t)(nw + 1), PH_LOAD, PH_JE, 100, true);
         pl.add(l.c.JT, N * N, PH_INV, PH_JE, 2);
-        pl.add(l.c.rscr, (size_t)nw * 4 * RSA, PH_FWD, PH_PASSB, 100, true);
+        pl.add(l.rscrF, (size_t)nw * 4 * RSF, PH_FWD, PH_FWD, 100, true);              // row scratch of the forward Laplacian (feature slots)
+        pl.add(l.c.rscr, (size_t)nw * 4 * RSA, PH_PASSA, PH_PASSB, 100, true);           // ... of the reverse passes (features + the pair's block of Jhat)
         // forward Laplacian
         pl.add(l.Lm0, (size_t)n * P, PH_FWD, PH_FWD, 70); pl.add(l.gu1, (size_t)n * HS, PH_FWD, PH_FWD, 70); pl.add(l.Lm1, (size_t)n * HT, PH_FWD, PH_FWD, 70);
-        pl.add(l.Am, (size_t)n * HS * P, PH_FWD, PH_FWD, 30); pl.add(l.Hk, (size_t)n * HS * D, PH_FWD, PH_FWD, 60);
+        pl.add(l.Am, (size_t)n * HS * P, PH_FWD, PH_FWD, 30); pl.add(l.Hk, (size_t)n * HS * D, PH_FWD, PH_FWD, 75);
         pl.add(l.Ls1, (size_t)n * HS, PH_FWD, PH_FWD, 70); pl.add(l.Su2, (size_t)n * HS, PH_FWD, PH_FWD, 70);
         pl.add(l.Lgb, HS, PH_FWD, PH_FWD, 99, true); pl.add(l.Ls2, (size_t)n * HS, PH_FWD, PH_FWD, 70);
         // reverse sweep
@@ -264,7 +265,6 @@ struct CgBig {
         pl.add(l.Vt, 2 * (size_t)n * F::SPV, PH_JC, PH_JD, 80); pl.add(l.Bmt, 2 * (size_t)n * F::SPB, PH_JC, PH_JD, 70);
         pl.add(l.Upt, 2 * N * P, PH_JC, PH_JD, 85);
         pl.add(l.Jp, N * N, PH_JD, PH_JE, 0);
-        pl.add(l.M, N * N, PH_JE, PH_JE, 0);
         const bool fits = pl.solve(lds_cap_doubles, l.lds_total, l.ws_total);
         l.ok = (fits && shapes_ok(n, nthr) && (mode == 1 || mode == 2)) ? 1 : 0;
         return l;
@@ -1066,6 +1066,7 @@ struct CgBig {
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
         const int lane = b.tid & 63, h = lane & 15, rg = lane >> 4, wave = b.tid >> 6, nw = b.nthr >> 6;
         const int grp = wave * 4 + rg, ngrp = nw * 4;
+        CG_STAMP_START(13)
         {   // row pass: lap m1_i[h], lap m0_i[f], |grad u1_i[h]|^2 (the two pair loops of CgLap::fwd_pair_sums in one walk over the pairs)
             double wc[D], wsn[D], w0c[D], w0s[D];
             const double bt = th[F::o_t0b + h], wd = th[F::o_t0w + 2 * D * HT + h], w0d = th[F::o_W0 + 2 * D * HS + h];
@@ -1074,7 +1075,7 @@ struct CgBig {
                 wc[a] = th[F::o_t0w + a * HT + h]; wsn[a] = th[F::o_t0w + (D + a) * HT + h];
                 w0c[a] = th[F::o_W0 + a * HS + h]; w0s[a] = th[F::o_W0 + (D + a) * HS + h];
             }
-            double* myrow = lds + l.c.rscr + (size_t)grp * RSF;
+            double* myrow = lds + l.rscrF + (size_t)grp * RSF;
             for (int i0 = 0; i0 < n; i0 += ngrp) {
                 if (i0 + wave * 4 >= n) break;
                 const int i = i0 + grp; const bool rowok = i < n; const int ic = rowok ? i : n - 1;
@@ -1127,6 +1128,7 @@ struct CgBig {
                 }
             }
         }
+        CG_STAMP_END(13)
         // per-particle factors of the dense x-gradient of u2:  A_i = Wa^T diag(sg1_i) W0^T (HS x P),  H_k = Wb^T G_k (HS x D)
         CgLap<D, HS, HT>::am_hk_mfma(b, th, n, sg1, G, Am, Hk);
         b.sync();
@@ -1138,8 +1140,10 @@ struct CgBig {
             const double g1 = sg1[e];
             Ls1[e] = g1 * lu + g1 * (1.0 - g1) * gu1[e];
         }
+        CG_STAMP_START(14)
         su2_pass(b, th, n, L, sh, ch, lds + o.wt, Am, Hk, Su2);
         b.sync();
+        CG_STAMP_END(14)
         for (int hh = b.tid; hh < HS; hh += b.nthr) {
             double a = 0;
             for (int i = 0; i < n; ++i) a += Ls1[i * HS + hh];
@@ -1370,7 +1374,7 @@ struct CgBig {
         const CgFastLds& o = l.c.o; const CgFastLds& oj = l.oj;
         const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *V = lds + o.V, *Bm = lds + o.Bm, *Up = lds + o.Up;
         const double* U = pl(l.Uk);
-        const double* JT = pl(l.c.JT); double* Jp = pl(l.Jp); double* M = pl(l.M);
+        const double* JT = pl(l.c.JT); double* Jp = pl(l.Jp);
         const double* zb = lds + l.c.zb; const double* Ta = pl(l.Ta); const double* Kd = lds + l.c.Kd;
         Jet2* jp = (Jet2*)(lds + l.jp);
         Jet2 *shj = jp + oj.sh, *chj = jp + oj.ch, *m0j = jp + oj.m0, *m1j = jp + oj.m1, *sg1j = jp + oj.sg1, *Gj = jp + oj.G;
@@ -1539,12 +1543,32 @@ struct CgBig {
                 p_re -= pr.re; p_im -= pr.im;
             }
         }
-        cg_gemm_wg(b, N, N, N, [&](int r, int k) { return JT[(size_t)k * N + r]; }, [&](int k, int c) { return Jp[(size_t)k * N + c]; },
-                   [&](int r, int c, double v) { M[(size_t)r * N + c] = v; });               // M = J^-1 J' (matrix cores)
-        b.sync();
-        for (int e = b.tid; e < N * N; e += b.nthr) {
-            const int al = cg_udiv(e, l.c.mN), ga = e - al * N;
-            t3 += M[(size_t)al * N + ga] * M[(size_t)ga * N + al];
+        // t3 = tr(M M), M = J^-1 J' = (J^-T)^T J', without storing M: a wave forms the tile M_IJ and, in the same lane layout, the transposed
+        // tile (M_JI)^T  (A operand: columns of J' in place of those of J^-T, B operand the other way round), multiplies them lane by lane and
+        // sums; I <= J only, the off-diagonal pairs count twice.  Operands straight from the two N x N matrices (rows of 16 lanes contiguous).
+        {
+            const int col = lane & 15, kq = lane >> 4;
+            const int tiles = (N + 15) >> 4, npair = tiles * (tiles + 1) / 2;
+            for (int tp = wave; tp < npair; tp += nw) {
+                int ti = 0, rem = tp;
+                while (rem >= tiles - ti) { rem -= tiles - ti; ++ti; }
+                const int tj = ti + rem;
+                const int ri = 16 * ti + col, cj = 16 * tj + col;
+                const bool iok = ri < N, jok = cj < N;
+                const int ric = iok ? ri : 0, cjc = jok ? cj : 0;
+                d4_t a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+#pragma unroll 4
+                for (int k0 = 0; k0 < N; k0 += 4) {
+                    const int k = k0 + kq; const bool kok = k < N; const size_t ko = (size_t)(kok ? k : 0) * N;
+                    const double ja = (iok && kok) ? JT[ko + ric] : 0.0, pb = (jok && kok) ? Jp[ko + cjc] : 0.0;
+                    const double pa = (iok && kok) ? Jp[ko + ric] : 0.0, jb = (jok && kok) ? JT[ko + cjc] : 0.0;
+                    a1 = F::mfma(ja, pb, a1);                  // M[16 ti + r][16 tj + c]
+                    a2 = F::mfma(pa, jb, a2);                  // M[16 tj + c][16 ti + r]
+                }
+                const double wgt = ti == tj ? 1.0 : 2.0;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) t3 = fma(wgt * a1[r4], a2[r4], t3);
+            }
         }
         red[0] = p_re; red[1] = p_im; red[2] = t2; red[3] = t3;
         CG_STAMP_END(19)

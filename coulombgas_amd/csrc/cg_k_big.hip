@@ -98,8 +98,8 @@ int cg_big_grad_lap(cg_ctx* c, const CgDev& m, const double* x, const int* sidx,
     const size_t capb = (size_t)cg_env_int("CG_BIG_LDS_KB", per_cu == 2 ? 79 : 159) * 1024;
     const auto bl = CgBig<D, HS, HT>::layout_gradlap(n, bnt, mode, capb / sizeof(double) - CG_TAB_DOUBLES);
     if (cg_env_int("CG_BIG_DEBUG", 0))
-        fprintf(stderr, "cg_big_grad_lap n=%d nt=%d mode=%d ok=%d lds %u doubles, ws %u doubles per workgroup; J %d JT %d Dm %d Dinv %d Ta %d Am %d Hk %d Bb %d Vb %d Ub %d Rb %d jp %d Vt %d Bmt %d Upt %d Jp %d M %d\n",
-                n, bnt, mode, bl.ok, bl.lds_total, bl.ws_total, bl.c.J, bl.c.JT, bl.c.Dm, bl.c.Dinv, bl.Ta, bl.Am, bl.Hk, bl.Bb, bl.Vb, bl.Ub, bl.Rb, bl.jp, bl.Vt, bl.Bmt, bl.Upt, bl.Jp, bl.M);
+        fprintf(stderr, "cg_big_grad_lap n=%d nt=%d mode=%d ok=%d lds %u doubles, ws %u doubles per workgroup; J %d JT %d Dm %d Dinv %d Ta %d Am %d Hk %d Bb %d Vb %d Ub %d Rb %d jp %d Vt %d Bmt %d Upt %d Jp %d\n",
+                n, bnt, mode, bl.ok, bl.lds_total, bl.ws_total, bl.c.J, bl.c.JT, bl.c.Dm, bl.c.Dinv, bl.Ta, bl.Am, bl.Hk, bl.Bb, bl.Vb, bl.Ub, bl.Rb, bl.jp, bl.Vt, bl.Bmt, bl.Upt, bl.Jp);
     if (!bl.ok) return 0;
     const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)bl.lds_total);
     const int chunk = std::min(B, c->cu_count * per_cu * cg_env_int("CG_BIG_ROUNDS", 4));

@@ -11,6 +11,7 @@ from coulombgas_amd import _lib
 GL = {20: "set-up (flow, J, J^-T, D^-1, g, K, T^a)", 21: "Slater part (J^T g, tr J^T H J)", 23: "forward Laplacian", 22: "reverse sweep (xbar)", 24: "jet pass"}
 GLS = {25: "set-up: x, k_occ, primal", 26: "set-up: Jacobian assembly", 27: "set-up: Slater matrix + both inverses", 28: "set-up: g, diag K", 18: "set-up: T^a (MFMA)",
        0: "set-up:   of which the real inverse (J^-T)",
+       13: "forward Laplacian: row pass (pair sums)", 14: "forward Laplacian: |grad u2|^2 (MFMA)",
        15: "reverse: pass A, Gbar, pass B", 16: "reverse: Rbar + dense chain", 17: "reverse: pair pass + xbar", 29: "jet: half-angle jets, pair sums, dense tangents",
        30: "jet: factor tangents, G pass", 31: "jet: pair pass (J', t2)", 19: "jet: traces (M = J^-1 J', t3)"}
 SC = {20: "set-up (flow, J, J^-T, D^-1, g)", 13: "pass A (U'bar, Bbar, Vbar, Wt partials)", 14: "Gbar (MFMA)", 19: "pass B (sg1bar, Ubar, W0 partials)",
