@@ -20,7 +20,9 @@ for sub, prefix in (("", tag + "_"), ("derivs", tag + "_derivs_")):
             continue
         shutil.copy(p, os.path.join(dst, prefix + f))
 with open(os.path.join(dst, tag + "_epoch_breakdowns.txt"), "w") as o:
-    for n, B in ((13, 8192), (29, 2048), (57, 512)):
+    for n, B in ((13, 8192), (29, 2048), (49, 512), (57, 512)):
+        if not os.path.exists(os.path.join(src, "epoch_breakdown_n%d.txt" % n)):
+            continue
         o.write("== n=%d B=%d (tools/epoch_breakdown.py %d %d)\n" % (n, B, n, B))
         o.write(open(os.path.join(src, "epoch_breakdown_n%d.txt" % n)).read() + "\n")
 
@@ -33,6 +35,8 @@ def counter(fname, name):
     raise SystemExit("counter %s not found in %s" % (name, fname))
 
 
+if os.path.exists(os.path.join(src, "traffic_derivs.json")):          # bench.py reads profiles/traffic_derivs.json (update_path / shapes)
+    shutil.copy(os.path.join(src, "traffic_derivs.json"), os.path.join(dst, "traffic_derivs.json"))
 tf = os.path.join(dst, "traffic_n13_B8192.json")
 t = json.load(open(tf))
 t["FETCH_SIZE_KB_per_launch"] = counter(tag + "_pmc_fetch_size_k_mcmc_n13_B8192.txt", "FETCH_SIZE")
