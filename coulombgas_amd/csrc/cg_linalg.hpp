@@ -2526,11 +2526,15 @@ __device__ __forceinline__ void cg_blocked_lu_dual2(const CgBlk& b, double* A, i
     const int npr = (N + PW - 1) / PW, npc = (n + PW - 1) / PW;
     for (int e = b.tid; e < 32; e += b.nthr) fl[e] = 0;
     b.sync();
+    // the complex chain rides on wave 5 when there is one (SIMD 1 either way -- waves go to the SIMDs round-robin -- but as the younger
+    // of the two waves there: 108.4 k -> 107.0 k cycles per pair at n = 57, 84.9 k -> 82.5 k at n = 49, tools/lu_bench; wave 4 = the real
+    // chain's SIMD costs 3 %)
+    const int cw = b.nthr >= 384 ? 5 : 1;
     if (wave == 0) {
         CG_STAMP_START(16)
         if (N <= 64) CgLu2::chain_real<1>(A, N, lda, lane, fl, res); else CgLu2::chain_real<2>(A, N, lda, lane, fl, res);
         CG_STAMP_END(16)
-    } else if (wave == 1) {
+    } else if (wave == cw) {
         CG_STAMP_START(17)
         CgLu2::chain_cplx(C, n, ldc, lane, fl, res);
         CG_STAMP_END(17)

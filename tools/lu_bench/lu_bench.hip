@@ -17,11 +17,14 @@ __device__ unsigned long long lu_trace[2][32];
 #include "../../coulombgas_amd/csrc/cg_common.hpp"
 #include "../../coulombgas_amd/csrc/cg_linalg.hpp"
 
+#ifndef LU_MAXT
+#define LU_MAXT 512
+#endif
 #ifndef LU_VARIANT
 #define LU_VARIANT 0
 #endif
 
-__global__ void __launch_bounds__(512, 1) k_lu(const double* __restrict__ tab, const double* __restrict__ Ag, const double* __restrict__ Cg,
+__global__ void __launch_bounds__(LU_MAXT, 1) k_lu(const double* __restrict__ tab, const double* __restrict__ Ag, const double* __restrict__ Cg,
                                                 int N, int n, int reps, double* out, unsigned long long* cyc) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
