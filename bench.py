@@ -172,6 +172,11 @@ def update_path_extras(eng, n, dim, L, sp, theta, sidx, x, peak_tflops, B_epoch=
          "grad_laplacian (k_grad_lap2, exact Laplacian: n d basis jet passes, src/logpsi.py:63-106)": med(lambda: eng.grad_laplacian_d(x_d, s_d, 0, None), reps=1),
          "scores (k_scores)": med(scores),
          "quantum Fisher matrix + mean score (k_fisher, reductions)": med(lambda: eng.scores_fisher_d(pack, 0, P * P))}
+
+    def fused():
+        x_d.version += 1
+        eng.grad_laplacian_d(x_d, s_d, 2, v_d, with_scores=True)
+    k["grad_laplacian + scores in one call (cg_grad_laplacian_scores: what an optimisation step runs; the set-up of the two is shared)"] = med(fused)
     eng.set_ewald(10, cg.kpoints(dim, 15), 10.0)
     k["ewald (k_ewald)"] = med(lambda: eng.ewald_d(x_d))
     b = np.random.default_rng(5).standard_normal(P)
@@ -289,6 +294,11 @@ def production_shapes(peak_tflops, mc_steps=50, stddev=0.1):
                 eng.scores_compute_d(x_d, s_d)
             gl = med(lambda: eng.grad_laplacian_d(x_d, s_d, 2, v_d)); sc = med(scores)
             r["grad_laplacian_ms"] = gl; r["scores_ms"] = sc
+
+            def fused():                                       # the two in one call, as an optimisation step runs them (shared set-up)
+                x_d.version += 1
+                eng.grad_laplacian_d(x_d, s_d, 2, v_d, with_scores=True)
+            r["grad_laplacian_scores_ms"] = med(fused)
             r["grad_laplacian_frac"] = grad_lap_flops(n, 2, mode=2) * B / (gl * 1e-3) / 1e12 / peak_tflops
             r["scores_frac"] = scores_flops(n, 2) * B / (sc * 1e-3) / 1e12 / peak_tflops
             tr = derivative_traffic(n)                         # HBM-side bytes per walker from the committed --pmc passes (not measured in this run)

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "cg_quantum_score": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "cg_quantum_fisher": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "cg_scores_compute": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "cg_grad_laplacian_scores": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_scores_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_scores_fisher": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cg_scores_mean": (C.c_int, [C.c_void_p, C.c_void_p]),

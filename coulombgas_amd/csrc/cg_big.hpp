@@ -142,6 +142,20 @@ struct CgBig {
         unsigned lds_total, ws_total; int ok;
     };
 
+    // What the score passes need from the set-up, parked in the workspace by the grad / Laplacian part of the fused kernel
+    // (k_gradlap_scores_big) and read back into the score layout: the two kernels keep their own plans, the set-up runs once.
+    struct Stash { int sh, ch, sg1, sg2, gbar, V, Bm, G, zb, Uk, s1, s2, m1, m0, JT /* only when the grad / Laplacian plan keeps J^-T in LDS */; unsigned total; };
+    static Stash stash_layout(int n) {
+        const int N = n * D;
+        Stash st; int at = 0;
+        auto take = [&](int& off, int size) { off = at; at += (size + 1) & ~1; };
+        take(st.sh, N); take(st.ch, N); take(st.sg1, n * HS); take(st.sg2, n * HS); take(st.gbar, HS);
+        take(st.V, n * F::SPV); take(st.Bm, n * F::SPB); take(st.G, n * F::SPG); take(st.zb, 2 * N); take(st.Uk, N * HS);
+        take(st.s1, n * HS); take(st.s2, n * HS); take(st.m1, n * HT); take(st.m0, n * P); take(st.JT, N * N);
+        st.total = (unsigned)at;
+        return st;
+    }
+
     static void plan_common(CgPlan& pl, LayC& c, int n, int nthr, int wt_last /* last phase that reads the staged two-particle weights */,
                             int x_last, int up_last) {
         const size_t N = (size_t)n * D;
@@ -695,6 +709,36 @@ struct CgBig {
         }
         setup2(b, th, n, L, pl, c, wf, pl(l.Uk));
         CG_STAMP_END(20)
+        score_passes(b, th, n, L, score, lds, ws, l, pl(c.JT));
+    }
+    // copy of `count` doubles (even, both sides 16-byte aligned) by the whole workgroup
+    static __device__ __forceinline__ void copy2(const CgBlk& b, double* dst, const double* src, int count) {
+        for (int e = 2 * b.tid; e < count; e += 2 * b.nthr) *(d2_t*)(dst + e) = *(const d2_t*)(src + e);
+    }
+    // the set-up results of the stash into the places the score layout gives them (fused kernel: instead of setup / setup2)
+    static __device__ __forceinline__ void scores_unstash(const CgBlk& b, int n, double* lds, double* ws, const LayS& l, const double* stash, const Stash& st) {
+        const int N = n * D;
+        const CgPl pl{lds, ws};
+        const CgFastLds& o = l.c.o;
+        auto ev = [](int v) { return (v + 1) & ~1; };
+        copy2(b, lds + o.sh, stash + st.sh, ev(N)); copy2(b, lds + o.ch, stash + st.ch, ev(N));
+        copy2(b, lds + o.sg1, stash + st.sg1, n * HS); copy2(b, lds + o.sg2, stash + st.sg2, n * HS);
+        copy2(b, lds + o.gbar, stash + st.gbar, HS);
+        copy2(b, lds + o.V, stash + st.V, ev(n * F::SPV)); copy2(b, lds + o.Bm, stash + st.Bm, ev(n * F::SPB)); copy2(b, lds + o.G, stash + st.G, ev(n * F::SPG));
+        copy2(b, lds + l.c.zb, stash + st.zb, 2 * N);
+        copy2(b, pl(l.Uk), stash + st.Uk, N * HS);
+        copy2(b, pl(l.s1k), stash + st.s1, n * HS); copy2(b, pl(l.s2k), stash + st.s2, n * HS);
+        copy2(b, pl(l.m1k), stash + st.m1, n * HT); copy2(b, pl(l.m0k), stash + st.m0, ev(n * P));
+        b.sync();
+    }
+    // everything after the set-up: reverse passes and the score row.  JT = J^-T (the score layout's own, or the one the grad / Laplacian
+    // part of the fused kernel left in its workspace)
+    static __device__ __forceinline__ void score_passes(const CgBlk& b, const double* __restrict__ th, int n, double L,
+                                                        double* __restrict__ score /* NP x 2 */, double* lds, double* ws, const LayS& l, const double* JT) {
+        const int N = n * D;
+        const CgPl pl{lds, ws};
+        const LayC& c = l.c;
+        const CgFastLds& o = c.o;
         CG_STAMP_START(13)
         const double *sh = lds + o.sh, *ch = lds + o.ch, *sg1 = lds + o.sg1, *sg2 = lds + o.sg2, *U = pl(l.Uk), *gbar = lds + o.gbar;
         const double* zr = lds + c.zb; const double* zi = zr + N;
@@ -703,7 +747,7 @@ struct CgBig {
                *u2b = pl(l.u2b), *u2i = pl(l.u2i), *u1b = pl(l.u1b), *u1i = pl(l.u1i), *m1b = lds + l.m1b, *m1i = lds + l.m1i,
                *su2 = lds + l.sums, *su2i = su2 + HS, *gbb = su2 + 2 * HS, *gbbi = su2 + 3 * HS,
                *pW0 = lds + l.pW0, *pWtJ = lds + l.pWtJ, *pWtR = lds + l.pWtR, *pWtI = lds + l.pWtI;
-        const Rev rv{sh, ch, sg1, sg2, U, lds + o.V, lds + o.Bm, lds + o.G, pl(c.JT), lds + c.rscr, Upb, Bb, Vb, lds + l.Gb, sg1b, Ub, Rb,
+        const Rev rv{sh, ch, sg1, sg2, U, lds + o.V, lds + o.Bm, lds + o.G, JT, lds + c.rscr, Upb, Bb, Vb, lds + l.Gb, sg1b, Ub, Rb,
                      lds + l.pS, pWtJ, pW0};
         const double rn = 1.0 / (double)n;
         const double c2c = CG_PI / (2.0 * L);
@@ -1577,14 +1621,31 @@ struct CgBig {
     static __device__ __forceinline__ void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                                                           const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                                                           int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
-                                                          double* __restrict__ lap /*2*/, double* lds, double* ws, const LayG& l) {
+                                                          double* __restrict__ lap /*2*/, double* lds, double* ws, const LayG& l,
+                                                          double* stash = nullptr, const Stash* st = nullptr) {
         const CgPl pl{lds, ws};
         const LayC& c = l.c;
         typename F::WFrag wf;
         const bool exact_phi = mode != 1;
         CG_STAMP_START(20)
         setup(b, th, xg, spk, sidx, n, L, pl, c, wf);
+        auto ev = [](int v) { return (v + 1) & ~1; };
+        if (stash) {        // (fused kernel) the primal temporaries of the score row, before the arena is reused
+            const CgFastLds& o = c.o;
+            copy2(b, stash + st->s1, lds + o.s1, n * HS); copy2(b, stash + st->s2, lds + o.s2, n * HS);
+            copy2(b, stash + st->m1, lds + o.m1, n * HT); copy2(b, stash + st->m0, lds + o.m0, ev(n * P));
+            b.sync();
+        }
         setup2(b, th, n, L, pl, c, wf, pl(l.Uk));
+        if (stash) {        // ... and the rest of what the score passes read
+            const CgFastLds& o = c.o; const int N = n * D;
+            copy2(b, stash + st->sh, lds + o.sh, ev(N)); copy2(b, stash + st->ch, lds + o.ch, ev(N));
+            copy2(b, stash + st->sg1, lds + o.sg1, n * HS); copy2(b, stash + st->sg2, lds + o.sg2, n * HS);
+            copy2(b, stash + st->gbar, lds + o.gbar, HS);
+            copy2(b, stash + st->V, lds + o.V, ev(n * F::SPV)); copy2(b, stash + st->Bm, lds + o.Bm, ev(n * F::SPB)); copy2(b, stash + st->G, lds + o.G, ev(n * F::SPG));
+            copy2(b, stash + st->zb, lds + c.zb, 2 * N);
+            copy2(b, stash + st->Uk, pl(l.Uk), N * HS);
+        }
         CG_STAMP_START(18)
         ta_gemm(b, n, pl(c.Dm), pl(c.Dinv), lds + c.kocc, pl(l.Ta));
         b.sync();

@@ -321,6 +321,7 @@ void cg_destroy(cg_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->bounce) (void)hipHostFree(c->bounce);
     if (c->d_scores) (void)hipFree(c->d_scores);
+    if (c->d_lay) (void)hipFree(c->d_lay);
     if (c->d_van) (void)hipFree(c->d_van);
     if (c->d_van_scores) (void)hipFree(c->d_van_scores);
     if (c->d_van_sp) (void)hipFree(c->d_van_sp);

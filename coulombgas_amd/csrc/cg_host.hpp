@@ -80,6 +80,8 @@ struct cg_ctx {
     // persistent workspace (derivative kernels)
     void* ws = nullptr; size_t ws_cap = 0;
     double* d_scores = nullptr; size_t scores_cap = 0; int scores_B = 0;     // resident per-sample scores (cg_scores_*)
+    void* d_lay = nullptr; int lay_tag = 0;     // small device copy of a kernel's layout struct (k_grad_lap2_scores: read where used instead of
+                                                // living in scalar registers through the whole kernel); lay_tag says whose
     CgVanModel van; double* d_van = nullptr; double* d_van_sp = nullptr; bool have_van = false;   // density-matrix Transformer (cg_van_*)
     double* d_van_scores = nullptr; size_t van_scores_cap = 0; int van_scores_B = 0;              // resident classical scores
     std::string err;

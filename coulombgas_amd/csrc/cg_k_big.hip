@@ -116,6 +116,73 @@ int cg_big_grad_lap(cg_ctx* c, const CgDev& m, const double* x, const int* sidx,
     return 1;
 }
 
+// Both at once for the optimisation step (src/VMC.py:35 and the jacrev of main.py:278 on the same walkers): the set-up -- flow, Jacobian,
+// the two inverses, g: 60 % of k_scores_big -- runs once; the grad / Laplacian part parks what the score passes need in the workspace
+// (CgBig::Stash), then the score passes run in their own layout.  Results: those of the two kernels, bit for bit.
+template <int D, int HS, int HT, int NT>
+__global__ void __launch_bounds__(NT, NT <= 256 ? 2 : 1) k_gradlap_scores_big(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab,
+                              const double* __restrict__ x, const int* __restrict__ sidx, int B, int w0, int mode, const double* __restrict__ v,
+                              double* __restrict__ grad, double* __restrict__ lap, double* __restrict__ score, double* ws,
+                              typename CgBig<D, HS, HT>::LayG lg, typename CgBig<D, HS, HT>::LayS ls, typename CgBig<D, HS, HT>::Stash st) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    __syncthreads();
+    CG_STAMP_INIT
+    constexpr int NP = CgFast<D, HS, HT>::NPARAM;
+    const int n = m.n, N = n * D, w = w0 + blockIdx.x;
+    if (w < B) {
+        double* wg = ws + (size_t)blockIdx.x * ((size_t)lg.ws_total + st.total + ls.ws_total);
+        double* stash = wg + lg.ws_total;
+        CgBig<D, HS, HT>::grad_laplacian(b, theta, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode, v + (size_t)w * N,
+                                         grad + (size_t)w * N * 2, lap + 2 * w, lds, wg, lg, stash, &st);
+        b.sync();
+        const double* JT = wg + (size_t)(~lg.c.JT);
+        if (lg.c.JT >= 0) {         // (small systems: J^-T sat in LDS, where the score layout is about to put its own arrays)
+            CgBig<D, HS, HT>::copy2(b, stash + st.JT, lds + lg.c.JT, N * N);
+            JT = stash + st.JT;
+            b.sync();
+        }
+        CgBig<D, HS, HT>::scores_unstash(b, n, lds, stash + st.total, ls, stash, st);
+        CgBig<D, HS, HT>::score_passes(b, theta, n, m.L, score + (size_t)w * NP * 2, lds, stash + st.total, ls, JT);
+    }
+    CG_STAMP_FLUSH
+#endif
+}
+
+// 1 launched, 0 not served (the caller runs the two kernels one after the other), < 0 error
+int cg_big_grad_lap_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap,
+                           double* score) {
+    constexpr int D = 2, HS = 16, HT = 16;
+    typedef CgBig<D, HS, HT> Big;
+    if (c->dim != D || c->hs != HS || c->ht != HT || (mode != 1 && mode != 2) || !v || c->n <= 16) return 0;
+    int rc;
+    const int n = c->n;
+    if (cg_env_int("CG_BIG", 1) == 0 || cg_env_int("CG_BIG_LAP", 1) == 0 || cg_env_int("CG_BIG_FUSED", 1) == 0) return 0;
+    const int bnt = cg_env_int("CG_BIG_NT", n * D <= 64 ? 256 : 512);
+    const int per_cu = bnt == 256 ? cg_env_int("CG_BIG_PER_CU", 2) : 1;
+    const size_t capb = (size_t)cg_env_int("CG_BIG_LDS_KB", per_cu == 2 ? 79 : 159) * 1024;
+    const auto lg = Big::layout_gradlap(n, bnt, mode, capb / sizeof(double) - CG_TAB_DOUBLES);
+    const auto ls = Big::layout_scores(n, bnt, capb / sizeof(double) - CG_TAB_DOUBLES);
+    if (!lg.ok || !ls.ok) return 0;
+    const auto st = Big::stash_layout(n);
+    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)std::max(lg.lds_total, ls.lds_total));
+    const size_t per_wg = (size_t)lg.ws_total + st.total + ls.ws_total;
+    const int chunk = std::min(B, c->cu_count * per_cu * cg_env_int("CG_BIG_ROUNDS", 4));
+    if ((rc = ensure_ws(c, sizeof(double) * (per_wg * chunk + 8)))) return rc;
+    auto go = [&](auto ntc) -> int {
+        constexpr int NT = decltype(ntc)::value;
+        if (int r = set_lds(c, k_gradlap_scores_big<D, HS, HT, NT>, lds)) return r;
+        for (int w0 = 0; w0 < B; w0 += chunk)
+            hipLaunchKernelGGL((k_gradlap_scores_big<D, HS, HT, NT>), dim3(std::min(chunk, B - w0)), dim3(NT), lds, c->stream, m, (const double*)c->d_theta,
+                               (const double*)c->d_spk, (const double*)c->d_tab, x, sidx, B, w0, mode, v, grad, lap, score, (double*)c->ws, lg, ls, st);
+        return 0;
+    };
+    if ((rc = bnt == 256 ? go(std::integral_constant<int, 256>{}) : go(std::integral_constant<int, 512>{}))) return rc;
+    return 1;
+}
+
 #if defined(CG_STAMPS)
 CG_STAMP_READER(cg_debug_stamps_big)         /* diagnostic builds only: the per-phase cycle counters of this unit's kernels */
 #endif

@@ -159,6 +159,76 @@ __global__ void __launch_bounds__(256) k_score_gemv(const double* __restrict__ S
 
 
 
+// Small systems (n <= 16, everything in LDS): k_grad_lap2 and k_scores in one kernel.  The set-up of the two is the same computation (61 % of
+// k_scores at n = 13): CgLap's set-up parks what the score sweep reads in the walker's workspace slot (CgLap::Stash: 39 KB at n = 13, written and
+// read back through the L2 of the workgroup's XCD, laid out like the score kernel's LDS image so that reading it is three flat copies), the grad / Laplacian runs on, then the sweep of cg_score.hpp runs in its own LDS layout.
+template <int D, int HS, int HT>
+__global__ void __launch_bounds__(256, 2) k_grad_lap2_scores(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab,
+                           const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode, const double* __restrict__ v,
+                           double* __restrict__ grad, double* __restrict__ lap, double* __restrict__ score, double* ws,
+                           typename CgLap<D, HS, HT>::Lay lg, const typename CgScore<D, HS, HT>::Lay* __restrict__ lsp /* device memory */,
+                           const typename CgLap<D, HS, HT>::Stash* __restrict__ stp /* device memory */, unsigned stash_doubles) {
+    double* lds = cg_dyn_lds + CG_TAB_DOUBLES;
+    const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
+    for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
+    constexpr int NP = CgFast<D, HS, HT>::NPARAM;
+    const int n = m.n, N = n * D, w = blockIdx.x;
+    const double* thg = theta;
+    if (lg.th_lds) {                     // (always, on this path; the branch keeps the pointer generic for the compiler: flat loads of the weights
+        double* th_l = lds + lg.th;      // overlap the ds_ queue -- 8 % faster than ds_read in k_grad_lap2)
+        for (int e = b.tid; e < NP; e += b.nthr) th_l[e] = theta[e];
+        thg = th_l;
+    }
+    __syncthreads();
+    CG_STAMP_INIT
+    if (w < B) {
+        double* stash = ws + (size_t)w * stash_doubles;
+        CgLap<D, HS, HT>::template grad_laplacian<true>(b, thg, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
+                                                        v + (size_t)w * N, grad + (size_t)w * N * 2, lap + 2 * w, lds, ws, lg, stash, stp);
+        b.sync();
+        const typename CgScore<D, HS, HT>::Lay ls = *lsp;          // (read here: ~60 scalar registers that the grad / Laplacian part does not carry)
+        double* th_l = lds + ls.th;
+        for (int e = b.tid; e < NP; e += b.nthr) th_l[e] = theta[e];
+        const double* th = ls.th >= 0 ? (const double*)th_l : theta;       // (as in k_scores: a pointer the compiler treats as generic)
+        CgScore<D, HS, HT>::unstash(b, n, lds, ls, stash);
+        CG_STAMP_START(21)
+        CgScore<D, HS, HT>::sweep(b, th, n, m.L, lds, ls, score + (size_t)w * NP * 2);
+        CG_STAMP_END(21)
+    }
+    CG_STAMP_FLUSH
+}
+
+// 1 launched, 0 not served, < 0 error
+static int small_grad_lap_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap,
+                                 double* score) {
+    constexpr int D = 2, HS = 16, HT = 16;
+    if (c->dim != D || c->hs != HS || c->ht != HT || (mode != 1 && mode != 2) || !v || cg_env_int("CG_SMALL_FUSED", 1) == 0) return 0;
+    int rc;
+    const int n = c->n;
+    const auto lg = CgLap<D, HS, HT>::layout(n, 256, mode, (size_t)CG_LAP_LDS_BYTES / sizeof(double) - CG_TAB_DOUBLES);
+    const auto ls = CgScore<D, HS, HT>::layout(n, 256, (size_t)CG_SCORE_LDS_BYTES / sizeof(double) - CG_TAB_DOUBLES);
+    if (!(lg.all_lds && lg.th_lds) || !ls.ok) return 0;
+    const auto st = CgScore<D, HS, HT>::stash_of(ls);
+    const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)std::max(lg.lds_total, ls.total));
+    if ((rc = ensure_ws(c, sizeof(double) * ((size_t)st.total * B + 64)))) return rc;
+    if (c->lay_tag != 1) {                     // the score layout, once per context, where the kernel reads it
+        if (!c->d_lay && hipMalloc(&c->d_lay, 4096) != hipSuccess) CG_FAIL(c, CG_ERR_HIP, "cg_grad_laplacian_scores: device allocation failed");
+        static_assert(sizeof(ls) + sizeof(st) <= 2048, "layout buffer");
+        CG_HIP(c, hipMemcpyAsync(c->d_lay, &ls, sizeof(ls), hipMemcpyHostToDevice, c->stream));
+        CG_HIP(c, hipMemcpyAsync((char*)c->d_lay + 2048, &st, sizeof(st), hipMemcpyHostToDevice, c->stream));
+        CG_HIP(c, hipStreamSynchronize(c->stream));
+        c->lay_tag = 1;
+    }
+    if ((rc = set_lds(c, k_grad_lap2_scores<D, HS, HT>, lds))) return rc;
+    hipLaunchKernelGGL((k_grad_lap2_scores<D, HS, HT>), dim3(B), dim3(256), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk,
+                       (const double*)c->d_tab, x, sidx, B, mode, v, grad, lap, score, (double*)c->ws, lg, (const CgScore<D, HS, HT>::Lay*)c->d_lay,
+                       (const CgLap<D, HS, HT>::Stash*)((const char*)c->d_lay + 2048), st.total);
+    return 1;
+}
+
+int cg_big_grad_lap_scores(cg_ctx* c, const CgDev& m, const double* x, const int* sidx, int B, int mode, const double* v, double* grad, double* lap,
+                           double* score);      // cg_k_big.hip
+
 extern "C" {
 
 int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, int mode, const double* v,
@@ -194,6 +264,33 @@ int cg_grad_laplacian(cg_ctx* c, const double* x, const int32_t* sidx, int B, in
     if (!launched) CG_FAIL(c, CG_ERR_UNSUPPORTED, "cg_grad_laplacian: configuration not instantiated");
     for (Arg* a : all) if ((rc = unstage(c, *a))) return rc;
     return finish(c);
+}
+
+/* cg_grad_laplacian AND cg_scores_compute of the same walkers in one call: what an optimisation step needs (src/VMC.py:35 for the local
+ * energies, then jax.jacrev(quantum_lossfn) of main.py:278 on the same x).  Where a fused kernel serves the configuration (device pointers,
+ * (dim 2, 16, 16) flow, Hutchinson modes: k_gradlap_scores_big at n > 16, k_grad_lap2_scores below it) the set-up of the two -- flow, Jacobian,
+ * both inverses -- runs once;
+ * otherwise the two calls run one after the other.  Results are those of the separate calls bit for bit. */
+int cg_grad_laplacian_scores(cg_ctx* c, const double* x, const int32_t* sidx, int B, int mode, const double* v, double* grad, double* lap) {
+    int rc = check_ready(c, "cg_grad_laplacian_scores", B); if (rc) return rc;
+    if (B <= 0) CG_FAIL(c, CG_ERR_ARG, "cg_grad_laplacian_scores: empty batch");
+    if (c->fast && c->ptr_mode == CG_PTR_DEVICE && (mode == 1 || mode == 2) && x && sidx && v && grad && lap) {
+        const size_t bytes = sizeof(double) * (size_t)B * c->P * 2;
+        if (c->scores_cap < bytes) {
+            if (c->d_scores) { CG_HIP(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_scores); c->d_scores = nullptr; c->scores_cap = 0; }
+            if (hipMalloc((void**)&c->d_scores, bytes) != hipSuccess)
+                CG_FAIL(c, CG_ERR_HIP, "cg_grad_laplacian_scores: %zu bytes for the per-sample scores could not be allocated", bytes);
+            c->scores_cap = bytes;
+        }
+        if ((rc = arena_reset(c))) CG_FAIL(c, rc, "cg_grad_laplacian_scores: arena");
+        c->scores_B = 0;                       // (not valid until the launch below has gone out)
+        rc = cg_big_grad_lap_scores(c, make_dev(c), x, (const int*)sidx, B, mode, v, grad, lap, (double*)c->d_scores);
+        if (rc == 0) rc = small_grad_lap_scores(c, make_dev(c), x, (const int*)sidx, B, mode, v, grad, lap, (double*)c->d_scores);
+        if (rc < 0) return rc;
+        if (rc == 1) { c->scores_B = B; return finish(c); }
+    }
+    if ((rc = cg_grad_laplacian(c, x, sidx, B, mode, v, grad, lap))) return rc;
+    return cg_scores_compute(c, x, sidx, B);
 }
 
 // Batch reductions over the resident score matrix, sliced over the batch so that the whole chip streams it (one slice

@@ -178,6 +178,30 @@ struct CgLap {
         return l;
     }
 
+    // Fused kernel (k_grad_lap2_scores): what the score sweep of cg_score.hpp reads from the set-up -- the two set-ups are the same
+    // computation -- parked in the walker's workspace slot while the rest of this kernel runs, then read into the score layout.  The slot
+    // mirrors the score layout's LDS image, so that reading it back is three flat copies (one memory latency, not one per array).
+    struct Stash { int m0, s1, sg1, m1, gbar, sg2, s2, U, V, Bm, G, pt, Jinv, zb; unsigned total; };     // (offsets: the score layout's own, see CgScore::stash_of)
+    static CG_DEVI void copyw(const CgBlk& b, double* dst, const double* src, int count) {
+        for (int e = b.tid; e < count; e += b.nthr) dst[e] = src[e];
+    }
+    // g_ia = T^a_ii = sum_j D_ij (i k_j^a) Dinv_ji, as the cotangents of z for the score sweep (zb: real parts, then imaginary parts) and,
+    // where asked, interleaved (gz).  ONE piece of code for k_scores and for the fused kernel: their results agree bit for bit.
+    static CG_DEVI void slater_g(const CgBlk& b, int n, const double* Dm, const double* Dinv, const double* kocc, double* gz, double* zb) {
+        const int N = n * D;
+        for (int e = b.tid; e < N; e += b.nthr) {
+            const int i = e / D, a = e - i * D;
+            double re = 0, im = 0;
+            for (int j = 0; j < n; ++j) {
+                const double ka = kocc[j * D + a];
+                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
+                re += -ka * p.im; im += ka * p.re;
+            }
+            if (gz) { gz[2 * e] = re; gz[2 * e + 1] = im; }
+            zb[e] = re; zb[N + e] = im;
+        }
+    }
+
     // block base pointers of one workgroup
     template <bool AL>
     struct Mem {
@@ -228,7 +252,8 @@ struct CgLap {
     template <bool AL>
     static CG_DEVI void setup(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                               const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
-                              const Mem<AL>& mem, const Lay& l, bool& early /* in: wanted; out: done */, bool& have_C) {
+                              const Mem<AL>& mem, const Lay& l, bool& early /* in: wanted; out: done */, bool& have_C,
+                              double* stash = nullptr, const Stash* st = nullptr) {
         const int N = n * D;
         const CgFastLds& o = l.o;
         double* da = mem.a + l.da; double* x = mem.p + l.x;
@@ -251,6 +276,15 @@ struct CgLap {
         pt_build(b, da + o.sh, da + o.ch, n, l.mn, mem.a + l.pt);          // (read after the barriers of the Jacobian assembly)
         F::jacobian(b, th, n, L, da, o, wf);
         CG_STAMP_END(26)
+        if (stash) {        // (fused kernel) the arena as the score sweep reads it, before the inverses' early work reuses the primal temporaries
+            b.sync();
+            copyw(b, stash + st->m0, da + o.m0, n * P); copyw(b, stash + st->s1, da + o.s1, n * HS); copyw(b, stash + st->sg1, da + o.sg1, n * HS);
+            copyw(b, stash + st->m1, da + o.m1, n * HT); copyw(b, stash + st->gbar, da + o.gbar, HS); copyw(b, stash + st->sg2, da + o.sg2, n * HS);
+            copyw(b, stash + st->s2, da + o.s2, n * HS); copyw(b, stash + st->U, da + o.U, N * HS); copyw(b, stash + st->V, da + o.V, n * (HT * D + 2));
+            copyw(b, stash + st->Bm, da + o.Bm, n * (HS * D + 2)); copyw(b, stash + st->G, da + o.G, n * (HS * D + 2));
+            copyw(b, stash + st->pt, mem.a + l.pt, n * n * PFS);
+            b.sync();
+        }
         CG_STAMP_START(27)
         double* Jc = mem.a + l.Jc; double* Jinv = mem.p + l.Jinv; double* Dc = mem.a + l.Dc; double* Dinv = mem.a + l.Dinv;
         bool inverted = false, early_done = false;
@@ -349,6 +383,10 @@ struct CgLap {
                 re += kk * p.re; im += kk * p.im;
             }
             Kd[2 * ((a * D + bb) * n + i)] = re; Kd[2 * ((a * D + bb) * n + i) + 1] = im;
+        }
+        if (stash) {        // J^-1 and the cotangents of z in the summation order of k_scores
+            copyw(b, stash + st->Jinv, Jinv, N * N);
+            slater_g(b, n, Dm, Dinv, kocc, nullptr, stash + st->zb);
         }
         b.sync();
         CG_STAMP_END(28)
@@ -1048,14 +1086,15 @@ struct CgLap {
     static CG_DEVI void grad_laplacian(const CgBlk& b, const double* __restrict__ th, const double* __restrict__ xg,
                                        const double* __restrict__ spk, const int* __restrict__ sidx, int n, double L,
                                        int mode, const double* __restrict__ v, double* __restrict__ grad /*N x 2*/,
-                                       double* __restrict__ lap /*2*/, double* lds, double* ws, const Lay& l) {
+                                       double* __restrict__ lap /*2*/, double* lds, double* ws, const Lay& l,
+                                       double* stash = nullptr, const Stash* st = nullptr) {
         const int N = n * D;
         const Mem<AL> mem(lds, ws, l);
         const bool exact_phi = mode != 1;
         bool early = exact_phi;                      // (set-up: granted on the wave-inverse path with waves to spare)
         CG_STAMP_START(20)
         bool have_C = false;
-        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l, early, have_C);
+        setup<AL>(b, th, xg, spk, sidx, n, L, mem, l, early, have_C, stash, st);
         CG_STAMP_END(20)
         double s_re, s_im, q_re = 0, q_im = 0;
         CG_STAMP_START(21)

@@ -149,19 +149,34 @@ struct CgScore {
             cg_inverse_complex(b, Dc.data(), n, n, Dinv, n, perm.data(), la, ar);
         }
 #endif
-        const double* Dm = lds + o.Dm;
-        double* gz = lds + l.gz; double* zb = lds + l.zb;
-        for (int e = b.tid; e < N; e += b.nthr) {                  // g_ia = T^a_ii = sum_j D_ij (i k_j^a) Dinv_ji
-            const int i = e / D, a = e - i * D;
-            double re = 0, im = 0;
-            for (int j = 0; j < n; ++j) {
-                const double ka = kocc[j * D + a];
-                const CgCplx p = cmul({Dm[2 * (i * n + j)], Dm[2 * (i * n + j) + 1]}, {Dinv[2 * (j * n + i)], Dinv[2 * (j * n + i) + 1]});
-                re += -ka * p.im; im += ka * p.re;
-            }
-            gz[2 * e] = re; gz[2 * e + 1] = im;
-            zb[e] = re; zb[N + e] = im;                            // cotangents of z: real part, imaginary part
-        }
+        LP::slater_g(b, n, lds + o.Dm, Dinv, kocc, lds + l.gz, lds + l.zb);      // g_ia = T^a_ii: cotangents of z, real and imaginary part
+        b.sync();
+    }
+    // (fused kernel k_grad_lap2_scores) instead of setup(): the same arrays, read from what CgLap's set-up parked in the workspace.  The slot
+    // mirrors this layout (stash_of), and what the sweep reads lies in three runs of it: [zb, sg1, sg2, m0, s1, m1, gbar, s2, U, (wt), pt],
+    // [V, Bm, G] and J^-1 -- three flat copies with 16-byte accesses.
+    static typename LP::Stash stash_of(const Lay& l) {
+        typename LP::Stash st;
+        const CgFastLds& o = l.o;
+        st.m0 = o.m0; st.s1 = o.s1; st.sg1 = o.sg1; st.m1 = o.m1; st.gbar = o.gbar; st.sg2 = o.sg2; st.s2 = o.s2; st.U = o.U; st.V = o.V; st.Bm = o.Bm; st.G = o.G;
+        st.pt = l.pt; st.Jinv = l.Jinv; st.zb = l.zb; st.total = l.total;
+        return st;
+    }
+    static CG_DEVI void unstash(const CgBlk& b, int n, double* lds, const Lay& l, const double* stash) {
+        const int N = n * D;
+        const CgFastLds& o = l.o;
+        auto ev = [](int v) { return (v + 1) & ~1; };
+#if defined(__HIPCC__)
+        typedef double d2_t __attribute__((ext_vector_type(2)));
+        auto run = [&](int from, int to) {
+            for (int e = from + 2 * b.tid; e < to; e += 2 * b.nthr) *(d2_t*)(lds + e) = *(const d2_t*)(stash + e);
+        };
+#else
+        auto run = [&](int from, int to) { for (int e = from + b.tid; e < to; e += b.nthr) lds[e] = stash[e]; };
+#endif
+        run(l.zb, l.pt + ev(n * n * PFS));
+        run(o.V, o.G + ev(n * (HS * D + 2)));
+        run(l.Jinv, l.Jinv + ev(N * N));
         b.sync();
     }
 

@@ -470,11 +470,19 @@ class Engine:
         out.version += 1
         return out
 
-    def grad_laplacian_d(self, x_d, sidx_d, mode, v_d=None):
+    def grad_laplacian_d(self, x_d, sidx_d, mode, v_d=None, with_scores=False):
+        """with_scores: the per-sample scores of the same walkers are left resident as well (cg_grad_laplacian_scores: one fused kernel where
+        the library has one, else the two calls) -- the scores_compute_d that follows in an optimisation step then finds them there"""
         B = x_d.shape[0]
         g = self.scratch("grad", (B, self.n, self.dim), complex_pairs=True)
         l = self.scratch("lap", (B,), complex_pairs=True)
-        self._dev_call(lib().cg_grad_laplacian, x_d.ptr, sidx_d.ptr, int(B), int(mode), v_d.ptr if v_d is not None else None, g.ptr, l.ptr)
+        key = (x_d.token, x_d.version, sidx_d.token, sidx_d.version, self._theta_version)
+        if with_scores and v_d is not None and getattr(self, "_score_key_d", None) != key:
+            self._score_key = self._score_key_d = None          # (also if the call below fails half-way)
+            self._dev_call(lib().cg_grad_laplacian_scores, x_d.ptr, sidx_d.ptr, int(B), int(mode), v_d.ptr, g.ptr, l.ptr)
+            self._score_key_d = key
+        else:
+            self._dev_call(lib().cg_grad_laplacian, x_d.ptr, sidx_d.ptr, int(B), int(mode), v_d.ptr if v_d is not None else None, g.ptr, l.ptr)
         g.version += 1; l.version += 1
         return g, l
 

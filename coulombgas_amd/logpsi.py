@@ -103,7 +103,9 @@ def make_logpsi_grad_laplacian(logpsi, forloop=True, hutchinson=False, logphi=No
     else:
         mode = _lib.CG_LAP_HUTCHINSON_SPLIT
 
-    def logpsi_grad_laplacian(x, params, state_indices, key):
+    def logpsi_grad_laplacian(x, params, state_indices, key, with_scores=False):
+        """with_scores (device arrays only; not in the reference's signature): also leave the per-sample scores d log Psi / d theta of
+        the same walkers resident -- make_loss asks for it, because the jacrev of main.py:278 follows on the same x"""
         eng = wf.engine(x, params)
         if _is_device(x):
             v_d = None
@@ -114,12 +116,13 @@ def make_logpsi_grad_laplacian(logpsi, forloop=True, hutchinson=False, logphi=No
                     from .mcmc import _seed_of
                     v_d = eng.randn_d("probe", x.shape, _seed_of(key))
             s_d = state_indices if _is_device(state_indices) else eng.asdevice(state_indices, "sidx", np.int32)
-            return eng.grad_laplacian_d(x, s_d, mode, v_d)
+            return eng.grad_laplacian_d(x, s_d, mode, v_d, with_scores=with_scores)
         v = _draw_v(key, np.shape(x)) if hutchinson else None
         return eng.grad_laplacian(x, state_indices, mode, v)
 
     logpsi_vmapped.wf = logpsi_grad_laplacian.wf = wf
     logpsi_grad_laplacian.mode = mode
+    logpsi_grad_laplacian.takes_with_scores = True
     return logpsi_vmapped, logpsi_grad_laplacian
 
 

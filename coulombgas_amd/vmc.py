@@ -40,11 +40,14 @@ def complex_clip(a, lo, hi):
     return np.where(lt(hi_c, m), hi_c, m)
 
 
-def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, beta, comm=None):
+def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, beta, comm=None, fuse_scores=True):
     """src/VMC.py:31-80.  `logpsi` is the vmapped closure returned by make_logpsi_grad_laplacian
     (main.py:254-259).  The two loss closures return the reference's (value, score) pair and carry
-    `.grad()`, which returns what jax.jacrev(lossfn) returns in main.py:277-278."""
+    `.grad()`, which returns what jax.jacrev(lossfn) returns in main.py:277-278.
+    fuse_scores: the grad / Laplacian call also leaves the per-sample scores of the same walkers on the device (one fused kernel at the
+    production sizes: the set-up of the two is the same), where quantum_lossfn.grad finds them; make_observable turns it off."""
     wf = logpsi.wf
+    fuse = fuse_scores and getattr(logpsi_grad_laplacian, "takes_with_scores", False)
 
     def observable_and_lossfn(params_van, params_flow, state_indices, x, key):
         cm = comm or get_comm()
@@ -58,7 +61,8 @@ def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, 
         else:
             lps = np.asarray(lps, dtype=np.float64)
             lps_d = eng.asdevice(lps, "logp_states") if lps.any() else None
-        grad, laplacian = logpsi_grad_laplacian(x_d, params_flow, s_d, key)                  # :35, stays on the device
+        grad, laplacian = (logpsi_grad_laplacian(x_d, params_flow, s_d, key, with_scores=True) if fuse
+                           else logpsi_grad_laplacian(x_d, params_flow, s_d, key))           # :35, stays on the device
         V = eng.ewald_d(x_d)                                                                 # :40
         Eloc, Floc, mom = eng.local_energy_d(grad, laplacian, V, lps_d, Vconst, beta)       # :39-42 + local means of :46-53
         cm.pmean_d(mom)                                                                      # :44-53, one 10-double all-reduce
@@ -125,5 +129,5 @@ def make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, 
 
 def make_observable(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, beta, comm=None):
     """Thin alias named by BASELINE.json's north star: returns only the observable dict of make_loss."""
-    f = make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, beta, comm)
+    f = make_loss(log_prob, logpsi, logpsi_grad_laplacian, kappa, G, L, rs, Vconst, beta, comm, fuse_scores=False)
     return lambda *a: f(*a)[0]

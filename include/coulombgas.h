@@ -142,6 +142,13 @@ int cg_quantum_fisher(cg_ctx* ctx, const double* x, const int32_t* state_idx, in
 int cg_scores_compute(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B);
 int cg_scores_vjp(cg_ctx* ctx, const double* w_re, const double* w_im, double* g_theta);
 int cg_scores_fisher(cg_ctx* ctx, double* fisher, double* score_mean);
+/* cg_grad_laplacian and cg_scores_compute on the same walkers in ONE call -- the pair an optimisation step makes (src/VMC.py:35 inside
+ * make_loss, then jax.jacrev(quantum_lossfn), main.py:278; XLA compiles the reference's two passes into one program as well).  With device
+ * pointers, the (dim 2, 16, 16) flow and a Hutchinson mode one fused kernel runs the common set-up (flow, Jacobian, the two
+ * inverses) once; every other case runs the two calls one after the other.  grad, lap and the resident scores are those of the separate
+ * calls bit for bit. */
+int cg_grad_laplacian_scores(cg_ctx* ctx, const double* x, const int32_t* state_idx, int B, int mode,
+                             const double* v, double* grad, double* lap);
 
 /* mean over the batch of the resident scores: score_mean (P,2) = mean_b S[b]  (src/sr.py:70 before its pmean; also
  * 1/2 of d/dtheta of quantum_score = 2 mean Re logPsi, src/VMC.py:75, main.py:278) */

@@ -174,7 +174,9 @@ class EmulEngine:
         out = self.logpsi(x, s)
         return out[..., 0] + 1j * out[..., 1]
 
-    def grad_laplacian_d(self, x, s, mode, v=None):
+    def grad_laplacian_d(self, x, s, mode, v=None, with_scores=False):
+        if with_scores:                                    # (the device engine's fused call: the scores of the same walkers stay resident)
+            self.scores_compute_d(x, s)
         return self.grad_laplacian(x, s, mode, v)
 
     def ewald_d(self, x):

@@ -951,6 +951,57 @@ def test_two_launch_chunks_at_the_production_batch(name, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("n,B,mode", [(57, 300, 2), (29, 70, 1), (20, 9, 2), (13, 33, 2), (29, 5, 0)])
+def test_grad_laplacian_and_scores_in_one_call(n, B, mode, monkeypatch):
+    """cg_grad_laplacian_scores (the pair of calls an optimisation step makes on the same walkers: src/VMC.py:35, then the jacrev of
+    main.py:278): gradient, Laplacian and the resident per-sample scores are those of cg_grad_laplacian + cg_scores_compute BIT FOR BIT --
+    where the fused kernel of csrc/cg_k_big.hip serves (n > 16, Hutchinson modes; n = 57 with a second launch chunk, n = 20 with a
+    different placement plan) and where the call falls back to the two kernels (n = 13, exact mode).  The scores are compared through
+    one-hot theta-VJPs (single rows of the score matrix, real and imaginary part), their batch mean and the Fisher matrix."""
+    from coulombgas_amd.engine import Engine, DeviceArray
+    from bench import synthetic
+    monkeypatch.setenv("CG_BIG_ROUNDS", "1")                   # n = 57: 256 walkers per launch
+    Emax = {13: 25, 20: 25, 29: 25, 57: 49}[n]
+    L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 3)
+    rng = np.random.default_rng(100 + n)
+    theta = theta + 0.05 * rng.standard_normal(theta.shape)
+    eng = Engine(n, 2, 2, 16, 16, L, sp); eng.set_params(theta)
+    P = eng.P
+    x_d = DeviceArray.from_numpy(eng, x); s_d = DeviceArray.from_numpy(eng, sidx, np.int32)
+    v_d = DeviceArray.from_numpy(eng, rng.standard_normal(x.shape)) if mode else None
+    rows = sorted({0, B // 2, B - 1})
+
+    def score_probe():
+        out = []
+        acc = eng.scratch("probe_acc", (3 * P + P * P,))
+        for r in rows:
+            for part in (0, 1):
+                w = np.zeros((2, B)); w[part, r] = 1.0
+                eng.scores_vjp_d(DeviceArray.from_numpy(eng, w[0]), DeviceArray.from_numpy(eng, w[1]), acc, 0)
+                out.append(eng.to_host(acc)[:P].copy())
+        eng.scores_mean_d(acc, P)
+        eng.scores_fisher_d(acc, 3 * P, P)
+        out.append(eng.to_host(acc)[P:].copy())
+        return out
+
+    g_d, l_d = eng.grad_laplacian_d(x_d, s_d, mode, v_d)
+    g0, l0 = eng.to_host(g_d).copy(), eng.to_host(l_d).copy()
+    eng.scores_compute_d(x_d, s_d)
+    ref = score_probe()
+    x_d.version += 1                                           # the resident scores no longer count as those of x_d
+    g_d, l_d = eng.grad_laplacian_d(x_d, s_d, mode, v_d, with_scores=True)
+    g1, l1 = eng.to_host(g_d).copy(), eng.to_host(l_d).copy()
+    if mode:
+        assert eng._score_key_d is not None                    # ... the fused call has left them there
+    eng.scores_compute_d(x_d, s_d)                             # (a look-up after a fused call; the computation in exact mode)
+    got = score_probe()
+    assert np.isfinite(g0).all() and np.isfinite(l0).all() and all(np.isfinite(a).all() for a in ref)
+    assert np.array_equal(g0, g1) and np.array_equal(l0, l1)
+    assert len(ref) == len(got) and all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert max(np.abs(a).max() for a in ref[:-1]) > 0
+    eng.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # f2: the autoregressive Transformer density matrix on the device (cg_van_sample / cg_van_log_prob)
 # ---------------------------------------------------------------------------------------------

@@ -36,3 +36,11 @@ g_d, l_d = eng.grad_laplacian_d(x_d, s_d, 2, v_d)[:2]
 g, lp = np.asarray(g_d), np.asarray(l_d)
 print("   checksums: |grad| %.15e  lap re %.15e im %.15e" % (np.abs(g).sum(), lp.real.sum() if np.iscomplexobj(lp) else lp[..., 0].sum(), lp.imag.sum() if np.iscomplexobj(lp) else lp[..., -1].sum()))
 timed("scores_compute (k_param_vjp)", scores)
+
+
+def fused():
+    x_d.version += 1
+    eng.grad_laplacian_d(x_d, s_d, 2, v_d, with_scores=True)
+
+
+timed("grad_laplacian + scores, one call", fused)
