@@ -245,7 +245,7 @@ def derivative_traffic(n):
     if not tj:
         return None
     out = {}
-    for kind in ("grad_laplacian", "scores"):
+    for kind in ("grad_laplacian", "scores", "grad_laplacian_scores"):
         if kind in tj:
             out[kind] = {k: tj[kind][k] for k in ("kernel", "traffic_bytes_per_walker", "algorithmic_bytes_per_walker", "traffic_over_algorithmic")}
     out["source"] = "profiles/traffic_derivs.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, per launch / walkers per launch)"

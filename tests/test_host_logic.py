@@ -112,6 +112,44 @@ def test_make_loss_host_algebra(monkeypatch):
     assert callable(cg.make_observable)
 
 
+def test_make_loss_asks_for_the_scores_with_the_laplacian(monkeypatch):
+    """make_loss runs the grad / Laplacian of a step as ONE call that also leaves the per-sample scores of the same walkers resident
+    (cg_grad_laplacian_scores on the device: the set-up of the two is shared); quantum_lossfn.grad then only looks them up.
+    make_observable has no gradient to follow and must not ask; an engine without the keyword (a foreign logpsi_grad_laplacian)
+    is called the reference's way."""
+    emul_engine.install(monkeypatch)
+    from tests.emul_engine import EmulEngine
+    import coulombgas_amd.logpsi as lp_mod
+    monkeypatch.setattr(lp_mod, "_is_device", lambda a: True)          # the emulated engine's arrays are numpy arrays: take the device branch
+    asked, computed = [], []
+    orig_gl, orig_sc = EmulEngine.grad_laplacian_d, EmulEngine.scores_compute_d
+    monkeypatch.setattr(EmulEngine, "grad_laplacian_d", lambda self, x, s, mode, v=None, with_scores=False:
+                        (asked.append(with_scores), orig_gl(self, x, s, mode, v, with_scores=with_scores))[1])
+    monkeypatch.setattr(EmulEngine, "scores_compute_d", lambda self, x, s: (computed.append(1), orig_sc(self, x, s))[1])
+    pb = _problem()
+    obs_fn, G, Vconst = build_loss(pb)
+    obs, closs, qloss = obs_fn(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"])
+    assert asked == [True] and len(computed) == 1
+    g1 = qloss.grad(pb["theta"], as_pytree=False)
+    # the same through the two separate calls
+    flow = cg.FermiNet(2, pb["hs"], pb["ht"], pb["L"])
+    logpsi_novmap = cg.make_logpsi(flow, pb["sp"], pb["L"])
+    logphi, logjacdet = cg.make_logphi_logjacdet(flow, pb["sp"], pb["L"])
+    logpsi, lgl = cg.make_logpsi_grad_laplacian(logpsi_novmap, hutchinson=True, logphi=logphi, logjacdet=logjacdet)
+    sep = cg.make_loss(lambda pv, si: pv, logpsi, lgl, pb["kappa"], G, pb["L"], pb["rs"], Vconst, pb["beta"], fuse_scores=False)
+    del asked[:]
+    obs2, _, qloss2 = sep(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"])
+    g2 = qloss2.grad(pb["theta"], as_pytree=False)
+    assert asked == [False] and obs2 == obs and all(np.array_equal(a, b) for a, b in zip(g1, g2))
+    del asked[:]
+    only_obs = cg.make_observable(lambda pv, si: pv, logpsi, lgl, pb["kappa"], G, pb["L"], pb["rs"], Vconst, pb["beta"])
+    assert only_obs(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"]) == obs and asked == [False]
+    plain = lambda x, params, state_indices, key: lgl(x, params, state_indices, key)          # the reference's four-argument form
+    plain.wf = lgl.wf
+    four = cg.make_loss(lambda pv, si: pv, logpsi, plain, pb["kappa"], G, pb["L"], pb["rs"], Vconst, pb["beta"])
+    assert four(pb["logp_states"], pb["theta"], pb["sidx"], pb["x"], pb["v"])[0] == obs
+
+
 def test_sample_stateindices_and_x(monkeypatch):
     """src/VMC.py:8-25: key split, sampler call, chain, wrap into [0, L)."""
     emul_engine.install(monkeypatch)

@@ -18,7 +18,7 @@ for cfg in "13 8192" "29 2048" "49 512" "57 512"; do
   for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_MFMA SQ_BUSY_CYCLES"; do
     nm=$(echo $pmc | cut -d' ' -f1 | tr 'A-Z' 'a-z')
     rocprofv3 --pmc $pmc -d $OUT/pmc_${nm}_n$1 -- python3 tools/deriv_timing.py $1 $2 2 > $OUT/pmc_${nm}_n$1.log 2>&1
-    python3 tools/profile_summary.py pmc $OUT/pmc_${nm}_n$1 k_grad_lap k_param_vjp k_scores k_gradlap_big > $OUT/pmc_${nm}_derivs_n$1_B$2.txt
+    python3 tools/profile_summary.py pmc $OUT/pmc_${nm}_n$1 k_grad_lap k_param_vjp k_scores k_gradlap_big k_gradlap_scores_big > $OUT/pmc_${nm}_derivs_n$1_B$2.txt
   done
   echo "done n=$1" 
 done

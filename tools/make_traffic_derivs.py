@@ -14,6 +14,8 @@ def algorithmic(kind, n):
     N = 2 * n
     if kind == "grad_laplacian":                               # x, state_idx, v in; grad (complex), lap (complex) out
         return 8 * N + 4 * n + 8 * N + 16 * N + 16
+    if kind == "grad_laplacian_scores":                        # the fused call: one set of inputs, both sets of outputs
+        return 8 * N + 4 * n + 8 * N + 16 * N + 16 + 16 * P
     return 8 * N + 4 * n + 16 * P                              # x, state_idx in; the (P, 2) score row out
 
 
@@ -43,7 +45,7 @@ for f in sorted(glob.glob(os.path.join(root, "pmc_fetch_size_derivs_n*_B*.txt"))
     for k in fe:
         if k not in wr or "FETCH_SIZE" not in fe[k] or "WRITE_SIZE" not in wr[k]:
             continue
-        kind = "grad_laplacian" if ("lap" in k) else "scores"
+        kind = "grad_laplacian_scores" if ("lap" in k and "scores" in k) else ("grad_laplacian" if ("lap" in k) else "scores")
         w = fe[k]["walkers_per_launch"]
         tot = (fe[k]["FETCH_SIZE"] + wr[k]["WRITE_SIZE"]) * 1024.0
         alg = algorithmic(kind, n)
