@@ -951,7 +951,7 @@ def test_two_launch_chunks_at_the_production_batch(name, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("n,B,mode", [(57, 300, 2), (29, 70, 1), (20, 9, 2), (13, 33, 2), (29, 5, 0)])
+@pytest.mark.parametrize("n,B,mode", [(57, 300, 2), (29, 70, 1), (20, 9, 2), (13, 33, 2), (29, 5, 0), (29, 1, 2), (16, 3, 1), (8, 2, 2)])
 def test_grad_laplacian_and_scores_in_one_call(n, B, mode, monkeypatch):
     """cg_grad_laplacian_scores (the pair of calls an optimisation step makes on the same walkers: src/VMC.py:35, then the jacrev of
     main.py:278): gradient, Laplacian and the resident per-sample scores are those of cg_grad_laplacian + cg_scores_compute BIT FOR BIT --
@@ -961,7 +961,7 @@ def test_grad_laplacian_and_scores_in_one_call(n, B, mode, monkeypatch):
     from coulombgas_amd.engine import Engine, DeviceArray
     from bench import synthetic
     monkeypatch.setenv("CG_BIG_ROUNDS", "1")                   # n = 57: 256 walkers per launch
-    Emax = {13: 25, 20: 25, 29: 25, 57: 49}[n]
+    Emax = 49 if n > 40 else 25
     L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 3)
     rng = np.random.default_rng(100 + n)
     theta = theta + 0.05 * rng.standard_normal(theta.shape)
@@ -999,6 +999,17 @@ def test_grad_laplacian_and_scores_in_one_call(n, B, mode, monkeypatch):
     assert np.array_equal(g0, g1) and np.array_equal(l0, l1)
     assert len(ref) == len(got) and all(np.array_equal(a, b) for a, b in zip(ref, got))
     assert max(np.abs(a).max() for a in ref[:-1]) > 0
+    if mode and B <= 9:
+        # the same entry point with HOST pointers (staged arguments: the two calls one after the other inside the library)
+        from coulombgas_amd._lib import lib, check
+        import ctypes as C
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        xh, sh_, vh = np.ascontiguousarray(x), np.ascontiguousarray(sidx, dtype=np.int32), np.ascontiguousarray(eng.to_host(v_d))
+        gh, lh = np.empty((B, n, 2, 2)), np.empty((B, 2))
+        check(lib().cg_grad_laplacian_scores(eng._ctx, p(xh), p(sh_), B, mode, p(vh), p(gh), p(lh)), eng._ctx)
+        eng._score_key = eng._score_key_d = None
+        assert np.array_equal(gh.reshape(-1), np.asarray(g0).view(np.float64).reshape(-1)) and np.array_equal(lh.reshape(-1), np.asarray(l0).view(np.float64).reshape(-1))
+        assert all(np.array_equal(a, b) for a, b in zip(ref, score_probe()))
     eng.close()
 
 

@@ -3,6 +3,8 @@
 --kernel-trace --stats run as CSV, or the mean of every --pmc counter per kernel.
    python tools/profile_summary.py stats gpurun_out/<dir> > profiles/<name>.csv
    python tools/profile_summary.py pmc   gpurun_out/<dir> [kernel-name-substring ...] > profiles/<name>.txt
+   python tools/profile_summary.py idle  gpurun_out/<dir> <kernel-name-substring>   (GPU idle time between launches, per stretch
+                                            from one launch of that kernel to the next: host gaps inside an epoch)
    python tools/profile_summary.py timeline gpurun_out/<dir> <kernel-name-substring> <count>   (the last <count> matching launches but 30:
                                             stream, start, duration, grid -- what runs beside what)"""
 import sys, glob, sqlite3, collections
@@ -14,6 +16,27 @@ if mode == "stats":
     print("kernel,calls,total_us,average_us,percent")
     for name, calls, total, avg, pct in c.execute("select * from top_kernels"):
         print('"%s",%d,%.3f,%.3f,%.4f' % (name.replace('"', "'"), calls, total, avg, pct))
+elif mode == "idle":
+    # GPU idle time between consecutive launches (any stream), split at every launch of the kernel named in argv[3] (one segment per
+    # epoch when that is k_mcmc): busy = union of the kernel intervals
+    sub = sys.argv[3]
+    rows = list(c.execute("select name, start, end from kernels order by start"))
+    marks = [i for i, r in enumerate(rows) if sub in r[0]]
+    for a, b in zip(marks[:-1], marks[1:]):
+        seg = rows[a:b]
+        t0, t1 = seg[0][1], rows[b][1]
+        busy, cur_s, cur_e, gaps = 0, seg[0][1], seg[0][2], []
+        for name, st, en in seg[1:]:
+            if st > cur_e:
+                gaps.append(((st - cur_e) / 1e3, name.split("(")[0][:40]))
+                busy += cur_e - cur_s; cur_s, cur_e = st, en
+            else:
+                cur_e = max(cur_e, en)
+        busy += cur_e - cur_s
+        tail = (t1 - cur_e) / 1e3
+        big = sorted(gaps, reverse=True)[:6]
+        print("segment %.3f ms: busy %.3f ms, idle %.3f ms in %d gaps + %.3f ms before the next %s; largest gaps (us, before): %s"
+              % ((t1 - t0) / 1e6, busy / 1e6, sum(g for g, _ in gaps) / 1e3, len(gaps), tail / 1e3, sub, ", ".join("%.0f %s" % g for g in big)))
 elif mode == "timeline":
     sub, cnt = sys.argv[3], int(sys.argv[4])
     rows = [r for r in c.execute("select name, start, end, stream_id, grid_x, grid_y from kernels order by start") if sub in r[0]]
