@@ -24,6 +24,14 @@
 #define CG_DEVN inline
 #endif
 
+// 1 in device code; 0 in the host builds of these headers (tests/host_emul: ONE thread walks every work item of the "workgroup", so
+// per-wave partial sums live in a single row and wave-level code paths are replaced by their scalar statement).  Branches on it are
+// ordinary `if` / `if constexpr`: both sides are compiled everywhere, and #if is left to the few places that name a device intrinsic.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CG_ON_DEVICE 1
+#else
+#define CG_ON_DEVICE 0
+#endif
 struct CgBlk {
     int tid, nthr;
     CG_DEVI void sync() const {
@@ -31,6 +39,7 @@ struct CgBlk {
         __syncthreads();
 #endif
     }
+    CG_DEVI int waves() const { return CG_ON_DEVICE ? nthr >> 6 : 1; }      // rows of the per-wave partial arrays
 };
 
 #define CG_PI 3.14159265358979323846264338327950288

@@ -106,11 +106,8 @@ struct CgDerivs {
             kocc[e] = spk[(size_t)sidx[j] * D + (e - j * D)];
         }
         b.sync();
-        const typename F::WFrag* wf = nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
         typename F::WFrag wfrag;
-        if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
-#endif
+        const typename F::WFrag* wf = F::frags(th, wfrag);                 // MFMA / DPP path of the sampler (device, 16 / 16), else the scalar one
         F::primal(b, th, (const double*)x, n, L, da, o, wf);
         LP::pt_build(b, da + o.sh, da + o.ch, n, mn ? mn : cg_div_magic((unsigned)n), ws + w.pt);
         F::jacobian(b, th, n, L, da, o, wf);

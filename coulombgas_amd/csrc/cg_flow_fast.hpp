@@ -126,6 +126,14 @@ struct CgFast {
         double* Jext;      // not null (large-n derivative kernels, cg_big.hpp): J is assembled there (any memory) instead of at lds + o.J,
                            // which then only serves as the pair-primal scratch
     };
+    // The MFMA / DPP code paths of primal() / jacobian() take their weights through a WFrag; a null pointer selects the scalar statement
+    // of the same arithmetic (host builds of these headers; widths other than 16 / 16).  One place decides: frags().
+    static CG_DEVI void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; w.wt_resident = false; w.Jext = nullptr; }
+    static CG_DEVI const WFrag* frags(const double* __restrict__ th, WFrag& w, bool inline_libm = true) {
+        if (!(CG_ON_DEVICE && HS == 16 && HT == 16)) return nullptr;
+        load_frags(th, w, inline_libm);
+        return &w;
+    }
     struct DenseP { double w0[2], b0, b2, wacb[12], wf[4], bf; };     // primal dense layers
     struct DenseJ { double ja[4], jb[4], jc[4]; };                     // R_i W_x^T
     struct DenseU { double w0t[4]; };
@@ -134,7 +142,6 @@ struct CgFast {
     static __device__ __forceinline__ d4_t mfma(double a, double bb, d4_t c) {
         return __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, c, 0, 0, 0);
     }
-    static __device__ __forceinline__ void load_frags(const double* __restrict__ th, WFrag& w, bool inline_libm = false) { w.th = th; w.inline_libm = inline_libm; w.wt_resident = false; w.Jext = nullptr; }
     static __device__ __forceinline__ void load_pair_cols(const double* __restrict__ th_in, WFrag& w) {
         const double* th = th_in;
         asm volatile("" : "+s"(th));      // opaque to LICM (see load_dense_p)
@@ -806,6 +813,14 @@ struct CgFast {
             }
         }
     }
+#else       // host builds: declarations only, so that the `if constexpr (CG_ON_DEVICE && ...)` branches of primal() / jacobian() parse
+    static bool primal_pairs_lds_fits(const CgBlk&, int);
+    static void primal_pairs_lds(const CgBlk&, const WFrag&, int, double*, const CgFastLds&);
+    static void primal_pairs_dpp(const CgBlk&, const WFrag&, int, double*, const CgFastLds&);
+    static void primal_dense_mfma(const CgBlk&, const WFrag&, const double*, int, double*, const CgFastLds&);
+    static void jacobian_mfma(const CgBlk&, const double*, const WFrag&, int, double, double*, const CgFastLds&);
+    static void primal_pairs_jet_dpp(const CgBlk&, const double*, int, Jet2*, const CgFastLds&);
+    static void g_pass_jet_dpp(const CgBlk&, const double*, int, double, Jet2*, const CgFastLds&);
 #endif
 
     // ---------------------------------------------------------------------------------------
@@ -826,22 +841,18 @@ struct CgFast {
         b.sync();
         CG_STAMP(1)
         bool pairs_done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+        if constexpr (CG_ON_DEVICE && sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
             if (wf) {
                 if (primal_pairs_lds_fits(b, n)) primal_pairs_lds(b, *wf, n, (double*)lds, o);
                 else primal_pairs_dpp(b, *wf, n, (double*)lds, o);
                 pairs_done = true;
             }
         }
-#endif
         // pair-primal: item (i,h)
         constexpr int HM = HT > P ? HT : P;          // lanes h < P also carry one raw-feature mean
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (CgIsJet<T>::value && HS == 16 && HT == 16) {
+        if constexpr (CG_ON_DEVICE && CgIsJet<T>::value && HS == 16 && HT == 16) {
             if (!pairs_done && hot < 0 && (b.nthr & 63) == 0) { primal_pairs_jet_dpp(b, th, n, (Jet2*)lds, o); pairs_done = true; }   // dense probe
         }
-#endif
         if constexpr (CgIsJet<T>::value) {
             // Sparse tangent of a basis-direction pass: rows i != hot see one jet pair (j = hot) and n - 1 double pairs;
             // the hot row's n x HM (j, h) units are spread over the whole workgroup through a scratch in J's slot (dead
@@ -942,14 +953,12 @@ struct CgFast {
         }
         b.sync();
         CG_STAMP(2)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+        if constexpr (CG_ON_DEVICE && sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
 #if defined(CG_EXP_NO_DENSE)
             if (wf) { for (int e = b.tid; e < n * D; e += b.nthr) z[e] = x[e] + 1e-3 * m1[e]; b.sync(); CG_STAMP(3) return; }
 #endif
             if (wf) { primal_dense_mfma(b, *wf, (const double*)x, n, (double*)lds, o); CG_STAMP(3) return; }
         }
-#endif
         // layer 0 of the one-particle stream: u1_i = W0^T m0_i + b0 (s0 = 0, src/flow.py:16-18,45)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int i = e / HS, h = e - i * HS;
@@ -1007,11 +1016,9 @@ struct CgFast {
         const int N = n * D;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
+        if constexpr (CG_ON_DEVICE && sizeof(T) == sizeof(double) && HS == 16 && HT == 16) {
             if (wf) { jacobian_mfma(b, th, *wf, n, L, (double*)lds, o); return; }
         }
-#endif
         // two-particle layer weights -> arena, [h][bias, w_0..w_{P-1}]: the Jacobian pass reads them with broadcast loads
         double* wt = (double*)(lds + o.wt);
         for (int e = b.tid; e < HT * (P + 1); e += b.nthr) {
@@ -1039,11 +1046,9 @@ struct CgFast {
         }
         // G pass: item (k,h)
         bool g_done = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (CgIsJet<T>::value && HS == 16 && HT == 16) {
+        if constexpr (CG_ON_DEVICE && CgIsJet<T>::value && HS == 16 && HT == 16) {
             if ((b.nthr & 63) == 0) { g_pass_jet_dpp(b, th, n, L, (Jet2*)lds, o); g_done = true; }
         }
-#endif
         if (!g_done)
         for (int e = b.tid; e < n * HS; e += b.nthr) {
             const int k = e / HS, h = e - k * HS;

@@ -264,11 +264,8 @@ struct CgLap {
             kocc[e] = spk[(size_t)sidx[j] * D + (e - j * D)];
         }
         b.sync();
-        const typename F::WFrag* wf = nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
         typename F::WFrag wfrag;
-        if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
-#endif
+        const typename F::WFrag* wf = F::frags(th, wfrag);                 // MFMA / DPP path of the sampler (device, 16 / 16), else the scalar one
         CG_STAMP_START(25)
         F::primal(b, th, (const double*)x, n, L, da, o, wf);
         CG_STAMP_END(25)
@@ -873,6 +870,9 @@ struct CgLap {
             }
         }
     }
+#else       // host builds: declared so that the `if constexpr (mfma_path)` branches of forward_laplacian parse; never instantiated
+    static void su2_mfma(const CgBlk&, const double*, int, double, double, double, const double*, const double*, const double*, const double*, double*);
+    static void am_hk_mfma(const CgBlk&, const double*, int, const double*, const double*, double*, double*);
 #endif
 
     template <bool AL>
@@ -888,17 +888,12 @@ struct CgLap {
         double *Ls1 = mem.a + l.Ls1, *Lgb = mem.a + l.Lgb, *Am = mem.a + l.Am, *Hk = mem.a + l.Hk, *Su2 = mem.a + l.Su2, *Ls2 = mem.a + l.Ls2;
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L), pl2 = 4.0 * c2c * c2c;
-        bool mfma_path = false;
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (HS == 16 && HT == 16) mfma_path = true;
-#endif
+        constexpr bool mfma_path = CG_ON_DEVICE && HS == 16 && HT == 16;      // (am_hk_mfma / su2_mfma: device code only)
 
         if (!pre) fwd_pair_sums(b, th, n, L, PT, Lm1, Lm0, gu1);
         // per-particle factors of the dense x-gradient of u2:  A_i = Wa^T diag(sg1_i) W0^T (HS x P),  H_k = Wb^T G_k (HS x D)
-        if (mfma_path) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (HS == 16 && HT == 16) am_hk_mfma(b, th, n, sg1, G, Am, Hk);
-#endif
+        if constexpr (mfma_path) {
+            am_hk_mfma(b, th, n, sg1, G, Am, Hk);
         } else {
             for (int e = b.tid; e < n * HS * P; e += b.nthr) {
                 const int i = e / (HS * P), r = e - i * HS * P, h = r / P, f = r - h * P;
@@ -926,10 +921,8 @@ struct CgLap {
         }
         // |grad_x u2_i[h]|^2:  E_ik[h][b] = d u2_i[h] / d x_kb  (k != i),  E_ii = -sum_k E_ik
         //   E_ik = -(1/n) A_i T_ik + H_k - (1/n) Wc^T diag(sig_t(u_ik)) Wt^T T_ik
-        if (mfma_path) {
-#if defined(__HIP_DEVICE_COMPILE__)
-            if constexpr (HS == 16 && HT == 16) su2_mfma(b, th, n, rn, c1, c2c, PT, da + o.wt, Am, Hk, Su2);
-#endif
+        if constexpr (mfma_path) {
+            su2_mfma(b, th, n, rn, c1, c2c, PT, da + o.wt, Am, Hk, Su2);
             b.sync();
             for (int h = b.tid; h < HS; h += b.nthr) {
                 double a = 0;

@@ -84,11 +84,20 @@ struct CgScore {
         return l;
     }
 
-    // sum over the lanes of a wave that hold the same unit h (lane = 16 (i mod 4) + h for the (i, h) work items, spsize = tpsize =
-    // 16), then lanes < 16 store the K values of their unit to this wave's row of the partial array.  Host shim (one thread walks
-    // every item): accumulate into row 0 (zeroed by the caller).
+    // Per-wave partial sums of the weight gradients.  Device: a lane accumulates its (i, h) items in registers; after its loop the lanes of
+    // a wave that hold the same unit h (lane = 16 (i mod 4) + h, spsize = tpsize = 16) are summed and lanes < 16 store the K values to
+    // this wave's row (wave_rows_store).  Host build (one thread walks every item): each item is added to row 0 (item_flush; the rows
+    // are zeroed by rows_zero), wave_rows_store has nothing left to do.
     template <int K>
-    static CG_DEVI void wave_rows_store(const CgBlk& b, double (&pw)[K], int h, double* part) {
+    static CG_DEVI void rows_zero(double* part) {
+        if (!CG_ON_DEVICE) for (int e = 0; e < 16 * K; ++e) part[e] = 0.0;
+    }
+    template <int K>
+    static CG_DEVI void item_flush(double (&pw)[K], int h, double* part) {
+        if (!CG_ON_DEVICE) for (int f = 0; f < K; ++f) { part[h * K + f] += pw[f]; pw[f] = 0; }
+    }
+    template <int K>
+    static CG_DEVI void wave_rows_store(const CgBlk& b, double (&pw)[K], double* part) {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int lane = b.tid & 63, wave = b.tid >> 6;
 #pragma unroll
@@ -97,10 +106,8 @@ struct CgScore {
             v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
             if (lane < 16) part[(wave * 16 + lane) * K + f] = v;
         }
-        (void)h;
 #else
-        for (int f = 0; f < K; ++f) part[h * K + f] += pw[f];
-        (void)b;
+        (void)b; (void)pw; (void)part;
 #endif
     }
 
@@ -118,11 +125,8 @@ struct CgScore {
             kocc[e] = spk[(size_t)sidx[j] * D + (e - j * D)];
         }
         b.sync();
-        const typename F::WFrag* wf = nullptr;
-#if defined(__HIP_DEVICE_COMPILE__)
         typename F::WFrag wfrag;
-        if constexpr (HS == 16 && HT == 16) { F::load_frags(th, wfrag, true); wf = &wfrag; }     // MFMA / DPP path of the sampler
-#endif
+        const typename F::WFrag* wf = F::frags(th, wfrag);                 // MFMA / DPP path of the sampler (device, 16 / 16), else the scalar one
         F::primal(b, th, (const double*)x, n, L, lds, o, wf);
         LP::pt_build(b, lds + o.sh, lds + o.ch, n, l.mn, lds + l.pt);
         F::jacobian(b, th, n, L, lds, o, wf);
@@ -198,10 +202,7 @@ struct CgScore {
         const double rn = 1.0 / (double)n;
         const double c1 = 2.0 * CG_PI / L, c2c = CG_PI / (2.0 * L);
         const unsigned mN = l.mN;
-#if !defined(__HIP_DEVICE_COMPILE__)
-        for (int e = 0; e < HS * P; ++e) pW0[e] = 0.0;
-        for (int e = 0; e < HT * KT; ++e) { pWtJ[e] = 0.0; pWtR[e] = 0.0; pWtI[e] = 0.0; }
-#endif
+        rows_zero<P>(pW0); rows_zero<KT>(pWtJ); rows_zero<KT>(pWtR); rows_zero<KT>(pWtI);          // (host build only)
         // (J6) J_ii = I - sum_{k!=i} J_ik  =>  Jhat_ik = Jbar_ik - Jbar_ii (k != i),  Jbar = 1/2 J^-T;  Jhat_ii = 0
         for (int e = b.tid; e < N * N; e += b.nthr) {
             const int r = cg_udiv(e, mN), c = e - r * N, i = r / D, k = c / D, bb = c - k * D;
@@ -237,10 +238,8 @@ struct CgScore {
             double pw[KT];
 #pragma unroll
             for (int f = 0; f < KT; ++f) pw[f] = 0;
-            int hh = 0;
             for (int e = b.tid; e < n * HT; e += b.nthr) {
                 const int i = e / HT, h = e - i * HT;
-                hh = h;
                 double wt[P]; const double bt = th[F::o_t0b + h];
 #pragma unroll
                 for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
@@ -285,25 +284,17 @@ struct CgScore {
                 }
 #pragma unroll
                 for (int a = 0; a < D; ++a) Vb[(i * D + a) * HT + h] = vb[a];
-#if !defined(__HIP_DEVICE_COMPILE__)
-                wave_rows_store<KT>(b, pw, h, pWtJ);
-#pragma unroll
-                for (int f = 0; f < KT; ++f) pw[f] = 0;
-#endif
+                item_flush<KT>(pw, h, pWtJ);
             }
-#if defined(__HIP_DEVICE_COMPILE__)
-            wave_rows_store<KT>(b, pw, hh, pWtJ);
-#endif
+            wave_rows_store<KT>(b, pw, pWtJ);
         }
         b.sync();
         {   // (J4) G adjoint, item (p,h): sg1bar_p[h] (first part) and partial W0bar;  (J3) second part of sg1bar
             double pw[P];
 #pragma unroll
             for (int f = 0; f < P; ++f) pw[f] = 0;
-            int hh = 0;
             for (int e = b.tid; e < n * HS; e += b.nthr) {
                 const int p = e / HS, h = e - p * HS;
-                hh = h;
                 double w_c[D], w_s[D];
 #pragma unroll
                 for (int a = 0; a < D; ++a) { w_c[a] = th[F::o_W0 + a * HS + h]; w_s[a] = th[F::o_W0 + (D + a) * HS + h]; }
@@ -330,15 +321,9 @@ struct CgScore {
 #pragma unroll
                     for (int f = 0; f < P; ++f) acc += Upb[(p * D + a) * P + f] * U[(p * D + a) * HS + h] * th[F::o_W0 + f * HS + h];
                 sg1b[e] = sb * (rn * rn) + acc * rn;
-#if !defined(__HIP_DEVICE_COMPILE__)
-                wave_rows_store<P>(b, pw, h, pW0);
-#pragma unroll
-                for (int f = 0; f < P; ++f) pw[f] = 0;
-#endif
+                item_flush<P>(pw, h, pW0);
             }
-#if defined(__HIP_DEVICE_COMPILE__)
-            wave_rows_store<P>(b, pw, hh, pW0);
-#endif
+            wave_rows_store<P>(b, pw, pW0);
         }
         for (int e = b.tid; e < N * HS; e += b.nthr) {             // (J3) Ubar_i[a][g]
             const int r = e / HS, g = e - r * HS, i = r / D;
@@ -406,10 +391,8 @@ struct CgScore {
             double pr[KT], pi[KT];
 #pragma unroll
             for (int f = 0; f < KT; ++f) { pr[f] = 0; pi[f] = 0; }
-            int hh = 0;
             for (int e = b.tid; e < n * HT; e += b.nthr) {
                 const int i = e / HT, h = e - i * HT;
-                hh = h;
                 double wt[P]; const double bt = th[F::o_t0b + h];
 #pragma unroll
                 for (int f = 0; f < P; ++f) wt[f] = th[F::o_t0w + f * HT + h];
@@ -429,23 +412,13 @@ struct CgScore {
                 }
 #pragma unroll
                 for (int f = 0; f < KT; ++f) { pr[f] += mr * a[f]; pi[f] += mi * a[f]; }
-#if !defined(__HIP_DEVICE_COMPILE__)
-                wave_rows_store<KT>(b, pr, h, pWtR); wave_rows_store<KT>(b, pi, h, pWtI);
-#pragma unroll
-                for (int f = 0; f < KT; ++f) { pr[f] = 0; pi[f] = 0; }
-#endif
+                item_flush<KT>(pr, h, pWtR); item_flush<KT>(pi, h, pWtI);
             }
-#if defined(__HIP_DEVICE_COMPILE__)
-            wave_rows_store<KT>(b, pr, hh, pWtR); wave_rows_store<KT>(b, pi, hh, pWtI);
-#endif
+            wave_rows_store<KT>(b, pr, pWtR); wave_rows_store<KT>(b, pi, pWtI);
         }
         b.sync();
         // ---- the score row, one owner thread per parameter (fixed summation order), real and imaginary part side by side
-#if defined(__HIP_DEVICE_COMPILE__)
-        const int nwp = b.nthr >> 6;
-#else
-        const int nwp = 1;
-#endif
+        const int nwp = b.waves();
         for (int e = b.tid; e < NP; e += b.nthr) {
             double ar = 0, ai = 0;
             if (e < F::o_fw) {                                          // final.b[a]
