@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_score_gemv(const double* __restrict__ S
 // read back through the L2 of the workgroup's XCD, laid out like the score kernel's LDS image so that reading it is three flat copies), the grad / Laplacian runs on, then the sweep of cg_score.hpp runs in its own LDS layout.
 template <int D, int HS, int HT>
 __global__ void __launch_bounds__(256, 2) k_grad_lap2_scores(CgDev m, const double* __restrict__ theta, const double* __restrict__ spk, const double* __restrict__ tab,
-                           const double* __restrict__ x, const int* __restrict__ sidx, int B, int mode, const double* __restrict__ v,
+                           const double* __restrict__ x, const int* __restrict__ sidx, int B, int w0, int mode, const double* __restrict__ v,
                            double* __restrict__ grad, double* __restrict__ lap, double* __restrict__ score, double* ws,
                            typename CgLap<D, HS, HT>::Lay lg, const typename CgScore<D, HS, HT>::Lay* __restrict__ lsp /* device memory */,
                            const typename CgLap<D, HS, HT>::Stash* __restrict__ stp /* device memory */, unsigned stash_doubles) {
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) k_grad_lap2_scores(CgDev m, const doub
     const CgBlk b{(int)threadIdx.x, (int)blockDim.x};
     for (int e = threadIdx.x; e < CG_TAB_DOUBLES; e += blockDim.x) cg_dyn_lds[e] = tab[e];
     constexpr int NP = CgFast<D, HS, HT>::NPARAM;
-    const int n = m.n, N = n * D, w = blockIdx.x;
+    const int n = m.n, N = n * D, w = w0 + blockIdx.x;        // (the batch goes in launches of gridDim.x walkers: one stash slot per workgroup)
     const double* thg = theta;
     if (lg.th_lds) {                     // (always, on this path; the branch keeps the pointer generic for the compiler: flat loads of the weights
         double* th_l = lds + lg.th;      // overlap the ds_ queue -- 8 % faster than ds_read in k_grad_lap2)
@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256, 2) k_grad_lap2_scores(CgDev m, const doub
     __syncthreads();
     CG_STAMP_INIT
     if (w < B) {
-        double* stash = ws + (size_t)w * stash_doubles;
+        double* stash = ws + (size_t)blockIdx.x * stash_doubles;
         CgLap<D, HS, HT>::template grad_laplacian<true>(b, thg, x + (size_t)w * N, spk, sidx + (size_t)w * n, n, m.L, mode,
                                                         v + (size_t)w * N, grad + (size_t)w * N * 2, lap + 2 * w, lds, ws, lg, stash, stp);
         b.sync();
@@ -210,7 +210,8 @@ static int small_grad_lap_scores(cg_ctx* c, const CgDev& m, const double* x, con
     if (!(lg.all_lds && lg.th_lds) || !ls.ok) return 0;
     const auto st = CgScore<D, HS, HT>::stash_of(ls);
     const size_t lds = sizeof(double) * (CG_TAB_DOUBLES + (size_t)std::max(lg.lds_total, ls.total));
-    if ((rc = ensure_ws(c, sizeof(double) * ((size_t)st.total * B + 64)))) return rc;
+    const int chunk = std::min(B, cg_env_int("CG_SMALL_FUSED_CHUNK", 16384));        // (77 KB of stash per walker in flight: 1.2 GB at most)
+    if ((rc = ensure_ws(c, sizeof(double) * ((size_t)st.total * chunk + 64)))) return rc;
     if (c->lay_tag != 1) {                     // the score layout, once per context, where the kernel reads it
         if (!c->d_lay && hipMalloc(&c->d_lay, 4096) != hipSuccess) CG_FAIL(c, CG_ERR_HIP, "cg_grad_laplacian_scores: device allocation failed");
         static_assert(sizeof(ls) + sizeof(st) <= 2048, "layout buffer");
@@ -220,8 +221,9 @@ static int small_grad_lap_scores(cg_ctx* c, const CgDev& m, const double* x, con
         c->lay_tag = 1;
     }
     if ((rc = set_lds(c, k_grad_lap2_scores<D, HS, HT>, lds))) return rc;
-    hipLaunchKernelGGL((k_grad_lap2_scores<D, HS, HT>), dim3(B), dim3(256), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk,
-                       (const double*)c->d_tab, x, sidx, B, mode, v, grad, lap, score, (double*)c->ws, lg, (const CgScore<D, HS, HT>::Lay*)c->d_lay,
+    for (int w0 = 0; w0 < B; w0 += chunk)
+        hipLaunchKernelGGL((k_grad_lap2_scores<D, HS, HT>), dim3(std::min(chunk, B - w0)), dim3(256), lds, c->stream, m, (const double*)c->d_theta, (const double*)c->d_spk,
+                       (const double*)c->d_tab, x, sidx, B, w0, mode, v, grad, lap, score, (double*)c->ws, lg, (const CgScore<D, HS, HT>::Lay*)c->d_lay,
                        (const CgLap<D, HS, HT>::Stash*)((const char*)c->d_lay + 2048), st.total);
     return 1;
 }

@@ -961,6 +961,7 @@ def test_grad_laplacian_and_scores_in_one_call(n, B, mode, monkeypatch):
     from coulombgas_amd.engine import Engine, DeviceArray
     from bench import synthetic
     monkeypatch.setenv("CG_BIG_ROUNDS", "1")                   # n = 57: 256 walkers per launch
+    monkeypatch.setenv("CG_SMALL_FUSED_CHUNK", "20")           # n = 13, B = 33: a second launch that reuses the stash slots of the first
     Emax = 49 if n > 40 else 25
     L, sp, theta, sidx, x = synthetic(n, 2, B, Emax, 3)
     rng = np.random.default_rng(100 + n)
