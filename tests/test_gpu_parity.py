@@ -1208,17 +1208,20 @@ def test_transformer_reverse_pass_on_device():
     eng.close()
 
 
-@pytest.mark.parametrize("n,M,B", [(5, 12, 70), (24, 40, 33), (33, 81, 20), (64, 113, 9)])
-def test_transformer_positions_in_parallel_reverse_pass(n, M, B, monkeypatch):
+@pytest.mark.parametrize("n,M,B,packed", [(5, 12, 70, 1), (24, 40, 33, 1), (33, 81, 20, 1), (64, 113, 9, 1), (13, 81, 37, 1), (17, 40, 9, 1),
+                                          (19, 81, 7, 1), (3, 12, 50, 1), (13, 81, 11, 0), (5, 12, 70, 0), (24, 40, 33, 0), (33, 81, 20, 0), (29, 81, 5, 1)])
+def test_transformer_positions_in_parallel_reverse_pass(n, M, B, packed, monkeypatch):
     """csrc/cg_van_par.hpp (the per-sample gradient of log p with the positions on the lanes of a wave, weight gradients on the matrix
     cores; shipped architecture, the default from n = 20 on), forced at ragged sizes -- fewer orbitals than one 16-column tile, n = 64
     (every lane but one a position), orbital counts that are no multiple of 16 -- against the host numpy backward at 1e-12 and
-    against torch autograd through the oracle's restatement (src/sampler.py:40-46, 65)."""
+    against torch autograd through the oracle's restatement (src/sampler.py:40-46, 65).  Up to 33 particles the PACKED variant runs
+    (64 / (n - 1) samples share a wave: 2 at n = 24 ... 33, 16 at n = 5, 5 at n = 13, 3 at n = 19 with ten lanes idle, 32 at n = 3; batches that are no
+    multiple of that); packed = 0 forces one sample per wave there."""
     import coulombgas_amd as cg
     from coulombgas_amd.engine import Engine
     from coulombgas_amd.sr import ravel_pytree, _ravel_batched
     from oracle import cg_ref as R
-    monkeypatch.setenv("CG_VAN_PAR", "1")
+    monkeypatch.setenv("CG_VAN_PAR", "1"); monkeypatch.setenv("CG_VAN_PACKED", str(packed))
     rng = np.random.default_rng(100 + n)
     sp = orbitals(2)[-M:] if M <= 25 else orbitals(2, 25)[:M] if M <= 81 else orbitals(2, 36)[:M]
     eng = Engine(n, 2, 2, 16, 16, box_length(n, 2), sp)
