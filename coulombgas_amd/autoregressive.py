@@ -98,11 +98,21 @@ class DeviceScores:
     .fisher_d() without the (B, P) matrix visiting the host; np.asarray(.) / .tree() download it (tests, diagnostics).  All
     host-visible results are in ravel_pytree order (sorted keys, like jax.flatten_util) -- perm maps it to the device's."""
 
+    _perms = {}          # (network architecture, dim) -> (parameter count, ravel order -> flat order): formed once, not per call
+
+    @classmethod
+    def layout(cls, network, dim):
+        key = (network.name, network.output_size, network.num_layers, network.model_size, network.num_heads, network.hidden_size, dim)
+        got = cls._perms.get(key)
+        if got is None:
+            from .sr import ravel_pytree
+            n = sum(int(np.prod(shp)) for leaves in network.param_shapes(dim).values() for shp in leaves.values())
+            got = cls._perms[key] = (n, ravel_pytree(unflat_params(network, np.arange(n), dim))[0].astype(np.int32))
+        return got
+
     def __init__(self, engine, network, dim, B):
-        from .sr import ravel_pytree
         self.engine, self.network, self.dim, self.B = engine, network, dim, B
-        n = sum(int(np.prod(shp)) for leaves in network.param_shapes(dim).values() for shp in leaves.values())
-        self.perm = ravel_pytree(unflat_params(network, np.arange(n), dim))[0].astype(np.int32)
+        n, self.perm = self.layout(network, dim)
         self.shape = (B, n)
 
     def fisher_d(self):
@@ -130,13 +140,21 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
     base = np.tril(np.ones((n, num_states), dtype=bool), k=num_states - n)
     dev = {"engine": engine}
 
+    bound = {"leaves": None, "eng": None}          # the parameter arrays the engine holds (by identity: a step calls in five times with one pytree)
+
     def _dev_engine(params):
         eng = dev["engine"]
         if eng is None:
             raise RuntimeError("autoregressive density matrix: no GPU engine attached (pass engine= / call .attach(engine); "
                                "coulombgas_amd.train attaches its own)")
+        leaves = [params[network.name]["x1hat"]] + [params[m][l] for m in _flat_modules(network) for l in ("b", "w")]
+        old = bound["leaves"]
+        if bound["eng"] is eng and old is not None and len(old) == len(leaves) and all(a is b_ for a, b_ in zip(old, leaves)) \
+                and getattr(eng, "_van_key", None) is not None and eng._van_key[3] is bound:
+            return eng                                   # the very arrays of the last call (nobody else has set parameters since)
         eng.van_set_params((num_states, network.num_layers, network.model_size, network.num_heads, network.hidden_size),
-                           sp_indices, flat_params(network, params, sp_indices.shape[1]))
+                           sp_indices, flat_params(network, params, sp_indices.shape[1]), owner=bound)
+        bound["leaves"], bound["eng"] = leaves, eng
         return eng
 
     def _mask(state_idx):
@@ -172,14 +190,14 @@ def make_autoregressive_sampler(network, sp_indices, n, num_states, mask_fn=Fals
         """sum_b w[b] * d log_prob_b / d params  (what jax.jacrev of a weighted sum of log-probabilities returns)."""
         eng = _dev_scores(params, state_idx)
         w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w")
-        g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1],)))
+        g = eng.van_scores_vjp_d(w_d, eng.scratch("van_vjp", (DeviceScores.layout(network, sp_indices.shape[1])[0],)))
         return unflat_params(network, eng.to_host(g), sp_indices.shape[1])
 
     def vjp_pair_d(params, state_idx, w1, w2):
         """both weighted sums jax.jacrev(classical_lossfn) needs (main.py:277) in ONE device buffer [sum_b w1[b] S_b | sum_b w2[b] S_b]
         (flat parameter order): the caller all-reduces it in place (main.py:280) before anything is read back."""
         eng = _dev_scores(params, state_idx)
-        Pv = DeviceScores(eng, network, sp_indices.shape[1], 0).shape[1]
+        Pv = DeviceScores.layout(network, sp_indices.shape[1])[0]
         out = eng.scratch("van_vjp_pair", (2 * Pv,))
         for k, w in enumerate((w1, w2)):
             w_d = w if hasattr(w, "ptr") else eng.asdevice(np.asarray(w, dtype=np.float64), "van_w%d" % k)

@@ -570,14 +570,15 @@ class Engine:
         copy); b, m, x are O(P) host vectors.  src/sr.py:88, 102-112."""
         b = _f64(b).reshape(-1)
         P = int(P if P is not None else b.size)
-        vec = self.scratch("solve_vec", (4 * P,))
+        vec = self.scratch("solve_vec_%d" % P, (4 * P,))          # (per size: the two solves of a hybrid step alternate, and a
+                                                                     # re-allocation is a hipFree -- a device-wide synchronisation)
         host = np.zeros(4 * P)
         host[:P] = b
         if center is not None:
             center = np.asarray(center).reshape(-1)
             host[P:2 * P] = center.real; host[2 * P:3 * P] = center.imag
         vec.upload(host)
-        work = self.scratch("solve_matrix", (P * P,))            # factor a copy: the caller's matrix stays intact
+        work = self.scratch("solve_matrix_%d" % P, (P * P,))    # factor a copy: the caller's matrix stays intact
         self.axpby_d(1.0, A_d, 0.0, work, count=P * P, x_index=index)
         self._dev_call(lib().cg_spd_solve, work.ptr, P, float(damping),
                        vec.ptr_at(P) if center is not None else None, vec.ptr_at(2 * P) if center is not None else None,
@@ -585,19 +586,21 @@ class Engine:
         return vec.numpy(3 * P, P)
 
     # -- density-matrix Transformer on the device (cg_van_*) -------------------------------
-    def van_set_params(self, cfg, sp_indices, flat):
+    def van_set_params(self, cfg, sp_indices, flat, owner=None):
         """cfg = (M, num_layers, model_size, num_heads, hidden_size); flat: parameters in the order of include/coulombgas.h.
-        Uploads only when something changed."""
+        Uploads only when something changed.  owner: whoever set them last (make_autoregressive_sampler uses it to skip the
+        flattening when it is handed the same parameter arrays again and nobody else has been here in between)."""
         flat = _f64(flat).ravel(); sp = _f64(sp_indices)
         key = getattr(self, "_van_key", None)
         if key is not None and key[0] == tuple(cfg) and np.array_equal(key[1], flat) and np.array_equal(key[2], sp):
+            self._van_key = key[:3] + (owner,)
             return
         M, nl, ms, nh, hs = (int(v) for v in cfg)
         need = lib().cg_van_num_params(M, nl, ms, nh, hs, self.dim)
         if need != flat.size:
             raise ValueError("Transformer parameter count %d, expected %d" % (flat.size, need))
         check(lib().cg_van_set_params(self._ctx, M, nl, ms, nh, hs, _p(sp), _p(flat)), self._ctx)
-        self._van_key = (tuple(cfg), flat.copy(), sp.copy())
+        self._van_key = (tuple(cfg), flat.copy(), sp.copy(), owner)
         self._van_version = getattr(self, "_van_version", 0) + 1
 
     def van_sample_d(self, B, seed, offset=0, unif=None):
