@@ -129,8 +129,12 @@ def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, lo
         acc["data"] = {k: acc["data"][k] + data[k] for k in DATA_KEYS}                 # :281-283
         acc["grads"] = grads if acc["grads"] is None else _tree(lambda a, b: a + b, acc["grads"], grads)
         acc["scores"] = scores if acc["scores"] is None else _tree(lambda a, b: a + b, acc["scores"], scores)
+        # acc_steps > 1: the ranks' Fisher matrices are accumulated locally and averaged over the ranks ONCE, in the final step (the
+        # pmean is linear; one all-reduce of the two matrices per update instead of one per accumulation step)
+        defer = acc_steps > 1 and hasattr(fishers_fn, "reduce_accumulated")
         if fishers_fn is not None:                                                     # :285-289
-            acc["fishers"] = acc_fisher(acc["fishers"], fishers_fn(params_van, params_flow, state_indices, x))
+            f = fishers_fn(params_van, params_flow, state_indices, x, reduce=False) if defer else fishers_fn(params_van, params_flow, state_indices, x)
+            acc["fishers"] = acc_fisher(acc["fishers"], f)
         if final_step:                                                                 # :291-307
             d = {k: v / acc_steps for k, v in acc["data"].items()}
             g = _tree(lambda a: a / acc_steps, acc["grads"]); s = _tree(lambda a: a / acc_steps, acc["scores"])
@@ -143,6 +147,8 @@ def make_update(observable_and_lossfn, optimizer, acc_steps, fishers_fn=None, lo
             if acc["fishers"] is not None:
                 fish = tuple(None if a is None else (a.eng.scale_d(a, 1.0 / acc_steps) if _is_device(a) else a / acc_steps)
                              for a in acc["fishers"])
+                if defer:
+                    fish = fishers_fn.reduce_accumulated(fish)
             updates, opt_state = optimizer.update((g_van, g_flow), opt_state, params=fish)
             if updates[0] is not None:
                 params_van = _sr.apply_updates(params_van, updates[0])

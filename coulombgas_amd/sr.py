@@ -122,30 +122,47 @@ def hybrid_fisher_sr(classical_score_fn, quantum_score_fn, damping, max_norm, co
     wf = quantum_score_fn.wf
     last_engine = [None]
 
-    def fishers_fn(params_van, params_flow, state_indices, x):
+    def fishers_fn(params_van, params_flow, state_indices, x, reduce=True):
         """src/sr.py:65-84.  The matrices are formed, all-reduced and returned in HBM (DeviceArrays on a GPU engine): the
         (P x P) quantum Fisher matrix and the mean score share one buffer and one all-reduce; nothing of size O(B P) or
-        O(P^2) visits the host."""
+        O(P^2) visits the host.
+        reduce=False: this rank's matrices, NOT averaged over the ranks -- make_update accumulates them over the acc_steps of an
+        update and averages the sums once (fishers_fn.reduce below): the mean over the ranks is linear, so acc_steps all-reduces of
+        P_van^2 + P^2 doubles (279 MB + 9 MB at the shipped sizes) become one."""
         cm = comm or get_comm()
         eng = wf.engine(x, params_flow)
         last_engine[0] = eng
+        red = (lambda a: cm.pmean_d(a)) if reduce else (lambda a: a)
         classical_fisher = None
         if classical_score_fn is not None:
             cs = classical_score_fn(params_van, state_indices)
             if hasattr(cs, "fisher_d"):                       # device Transformer: the scores never leave the GPU
-                classical_fisher = cm.pmean_d(cs.fisher_d())
+                classical_fisher = red(cs.fisher_d())
             else:
-                classical_fisher = cm.pmean_d(eng.fisher_real_d(_ravel_batched(cs)))     # :77-79
+                classical_fisher = red(eng.fisher_real_d(_ravel_batched(cs)))            # :77-79
         x_d = eng.asdevice(x, "x")
         s_d = eng.asdevice(state_indices, "sidx", np.int32)
         eng.scores_compute_d(x_d, s_d)                                                   # :69-71 (shared with the theta-VJP)
         P = eng.P
         pack = eng.scratch("fisher_pack", (P * P + 2 * P,))
         eng.scores_fisher_d(pack, 0, P * P)
-        cm.pmean_d(pack)                                                                 # :73, :80-82 in one all-reduce
+        red(pack)                                                                        # :73, :80-82 in one all-reduce
         qf = eng.view(pack, 0, (P, P))
         sm = eng.to_host_slice(pack, P * P, 2 * P)
         return classical_fisher, qf, sm[0::2] + 1j * sm[1::2]
+
+    def reduce_accumulated(fishers):
+        """the pmean of src/sr.py:70-76 applied to the SUMS over the accumulation steps (what fishers_fn(reduce=False) returned, added
+        up): device matrices in place, the complex score mean through the host"""
+        cm = comm or get_comm()
+        cf, qf, qm = fishers
+        if cf is not None:
+            cf = cm.pmean_d(cf) if hasattr(cf, "ptr") else cm.pmean(cf)
+        qf = cm.pmean_d(qf) if hasattr(qf, "ptr") else cm.pmean(qf)
+        qm = np.asarray(qm)
+        both = np.asarray(cm.pmean(np.concatenate([qm.real, qm.imag])))
+        return cf, qf, both[:qm.size] + 1j * both[qm.size:]
+    fishers_fn.reduce_accumulated = reduce_accumulated
 
     def init_fn(params):
         return EmptyState()

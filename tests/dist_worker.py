@@ -84,8 +84,19 @@ def main():
     cs_full = np.random.default_rng(99).standard_normal((pb["x"].shape[0], 5))
     fishers_fn, _ = cg.hybrid_fisher_sr(lambda pv, si: cs_full[sl], qscore, 1e-3, 1e-3)
     cf, qf, qm = fishers_fn(None, flow.unravel(pb["theta"], pb["x"].shape[-1]), pb["sidx"][sl], pb["x"][sl])
+    cf, qf = np.array(cf), np.array(qf)                                    # (the engine's buffers are overwritten by the next call)
+    # two accumulation steps: all-reducing each step's matrices (src/sr.py:70-76 as written) against accumulating this rank's matrices
+    # and all-reducing the sums once (make_update at acc_steps > 1)
+    pf = flow.unravel(pb["theta"], pb["x"].shape[-1])
+    xb = pb["x"][sl] + 0.05
+    copy3 = lambda f: (np.array(f[0]), np.array(f[1]), np.array(f[2]))
+    e0 = copy3(fishers_fn(None, pf, pb["sidx"][sl], pb["x"][sl])); e1 = copy3(fishers_fn(None, pf, pb["sidx"][sl], xb))
+    each = [a + b for a, b in zip(e0, e1)]
+    l0 = copy3(fishers_fn(None, pf, pb["sidx"][sl], pb["x"][sl], reduce=False)); l1 = copy3(fishers_fn(None, pf, pb["sidx"][sl], xb, reduce=False))
+    once = fishers_fn.reduce_accumulated(tuple(a + b for a, b in zip(l0, l1)))
+    defer_err = max(float(np.abs(np.asarray(a) - np.asarray(b)).max() / np.abs(np.asarray(a)).max()) for a, b in zip(each, once))
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), obs=np.array([obs[k] for k in sorted(obs)]), qv=np.array(qv), g=g, s=s,
-             rate=rate, x=x, tvE=float(np.abs(obs_fn.Eloc - obs["E_mean"]).mean()), cf=cf, qf=qf, qm=qm)
+             rate=rate, x=x, tvE=float(np.abs(obs_fn.Eloc - obs["E_mean"]).mean()), cf=cf, qf=qf, qm=qm, defer_err=defer_err)
     dist.barrier()
     dist.destroy_process_group()
 

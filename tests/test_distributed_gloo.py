@@ -24,6 +24,8 @@ def test_two_ranks_match_single_process(tmp_path, monkeypatch):
     for k in ("obs", "qv", "g", "s", "rate", "cf", "qf", "qm"):
         assert np.array_equal(r0[k], r1[k]), k
     assert not np.array_equal(r0["x"], r1["x"])                 # different walkers per rank
+    # Fisher matrices accumulated per rank and all-reduced once == all-reduced per accumulation step (the pmean is linear)
+    assert float(r0["defer_err"]) < 1e-14 and float(r1["defer_err"]) < 1e-14
     # single process, full batch
     from tests import emul_engine
     from tests.test_host_logic import _problem, build_loss
