@@ -33,9 +33,10 @@ if "--host-arrays" not in sys.argv:          # default: the walkers live in HBM 
     from coulombgas_amd.engine import DeviceArray
     x = DeviceArray.from_numpy(flow.engine(n, 2, sp), x)
 T = {}
+EP = 8                                       # epochs 1 .. EP - 1 are reported (median per phase: a host hiccup in one epoch does not move it)
 def tm(name, fn):
-    t0 = time.perf_counter(); r = fn(); T[name] = T.get(name, 0.0) + time.perf_counter() - t0; return r
-for ep in range(4):
+    t0 = time.perf_counter(); r = fn(); T.setdefault(name, {}); T[name][ep] = T[name].get(ep, 0.0) + time.perf_counter() - t0; return r
+for ep in range(EP):
     if ep == 1: T.clear()
     key, sidx, x, acc = tm("sample", lambda: cg.sample_stateindices_and_x(key, samp, pv, logp, x, p0, 50, 0.1, L))
     data, closs, qloss = tm("observable (grad_lap+ewald)", lambda: loss(pv, p0, sidx, x, key))
@@ -53,6 +54,8 @@ for ep in range(4):
     p0 = tm("apply", lambda: cg.apply_updates(p0, uf))
     if uv is not None:
         pv = tm("apply", lambda: cg.apply_updates(pv, uv))
+med = lambda d: sorted(d.values())[len(d) // 2]
 for k, v in T.items():
-    print("%-30s %7.1f ms" % (k, v / 3 * 1e3))
-print("%-30s %7.1f ms" % ("total", sum(T.values()) / 3 * 1e3))
+    print("%-30s %7.1f ms" % (k, med(v) * 1e3))
+tot = {e: sum(v.get(e, 0.0) for v in T.values()) for e in range(1, EP)}
+print("%-30s %7.1f ms   (median of %d epochs; fastest %.1f, slowest %.1f)" % ("total", med(tot) * 1e3, EP - 1, min(tot.values()) * 1e3, max(tot.values()) * 1e3))
