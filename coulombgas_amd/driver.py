@@ -269,4 +269,7 @@ def train(flow, params_flow, sp_indices, n, dim, L, rs, beta, batch, epochs, sam
                 os.makedirs(ckpt_path, exist_ok=True)
                 save_data({"keys": ks, "x": xs, "params_van": params_van, "params_flow": params_flow, "opt_state": opt_state},
                           ckpt_filename(i, ckpt_path))
+            # the run goes on from the key it has just written (two words per rank, the reference's key format, cannot hold a
+            # SeedSequence's spawn history): a run resumed from this file then retraces this one draw for draw (main.py:217-223)
+            key = np.random.SeedSequence([int(v) for v in np.atleast_2d(ks)[cm.rank].ravel()])
     return params_van, params_flow, rows

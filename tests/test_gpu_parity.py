@@ -1247,6 +1247,40 @@ def test_transformer_positions_in_parallel_reverse_pass(n, M, B, packed, monkeyp
     eng.close()
 
 
+@pytest.mark.parametrize("finite_T", [False, True])
+def test_resumed_run_retraces_the_uninterrupted_one(finite_T, tmp_path):
+    """main.py:217-223 + 374-381 on the device path: a run interrupted after its checkpoint at epoch 2 and resumed (walkers, keys,
+    parameters, optimizer state from the file) produces epochs 3 and 4 of the uninterrupted run -- rows and parameters bit for bit;
+    zero temperature (SR on the flow) and finite temperature (the Transformer density matrix sampled and trained on the GPU too)."""
+    import coulombgas_amd as cg
+    n, dim = 13, 2
+    L = box_length(n, dim); sp = orbitals(2, 25)
+    flow = cg.FermiNet(2, 16, 16, L)
+    p0 = flow.init(5, np.zeros((n, dim)))
+    kw = dict(rs=10.0, beta=1 / (4 * 0.15), batch=48, mc_therm=2, mc_steps=10, seed=11, sr=(1e-3, 1e-3), ckpt_every=2)
+    if finite_T:
+        van = cg.Transformer(sp.shape[0], 2, 16, 4, 32)
+        pv = van.init(np.random.default_rng(3), sp[:n])
+        make = lambda: cg.make_autoregressive_sampler(van, sp, n, sp.shape[0])
+    else:
+        pv = None
+        samp = cg.GroundStateSampler(n, sp.shape[0])
+        make = lambda: (samp, samp.log_prob)
+
+    def run(epochs, path, **more):
+        sampler, log_prob = make()
+        return cg.train(flow, p0, sp, n, dim, L, epochs=epochs, sampler=sampler, log_prob=log_prob, params_van=pv, ckpt_path=str(path), **kw, **more)
+    vA, fA, rowsA = run(4, tmp_path / "a")
+    run(2, tmp_path / "b")
+    vB, fB, rowsB = run(4, tmp_path / "b", epoch_finished=2)
+    assert len(rowsA) == 4 and rowsB == rowsA[2:]
+    assert np.array_equal(flow.ravel(fA, dim), flow.ravel(fB, dim))
+    if finite_T:
+        from coulombgas_amd.sr import ravel_pytree
+        assert np.array_equal(ravel_pytree(vA)[0], ravel_pytree(vB)[0])
+        assert not np.array_equal(ravel_pytree(vA)[0], ravel_pytree(pv)[0])
+
+
 def test_freefermion_pretraining_on_device():
     """f4 (src/freefermion/pretraining.py:34-108) with the density matrix sampled and evaluated on the GPU and the classical
     Fisher matrix formed there: natural-gradient pre-training of a small Transformer lowers F = <log p / beta + E> towards the

@@ -304,6 +304,9 @@ def test_train_checkpoint_and_resume(monkeypatch, tmp_path):
     assert [int(r.split()[0]) for r in rows4] == [3, 4] and rows == rows4
     assert not np.array_equal(flow.ravel(pf4, dim), flow.ravel(pf2, dim))
     assert cg.load_data(cg.ckpt_filename(4, str(tmp_path)))["opt_state"]["count"] == 4
+    # ... and retraces an uninterrupted run draw for draw (the run goes on from the key it writes into the file)
+    _, pfA, rowsA = cg.train(flow, p0, sp, n, dim, L, epochs=4, optimizer=cg.adam(1e-2), **dict(kw, ckpt_path=str(tmp_path / "straight")))
+    assert rowsA[2:] == rows4 and np.array_equal(flow.ravel(pfA, dim), flow.ravel(pf4, dim))
 
 
 def test_checkpoint_interop(tmp_path):
